@@ -1,0 +1,153 @@
+/* rustracer_hip.h — C ABI of the MI355X (gfx950) trace/shade library, librustracer_hip.so.
+ *
+ * This is the drop-in boundary for rustracer's per-pixel hot path.  The reference has no FFI of
+ * its own (one binary crate, `mod` declarations only: src/main.rs:4-8); these entry points are
+ * what a `-sys` crate would bind in order to replace the bodies of
+ *   RaytracerInner::do_render      (src/raytracer.rs:167-221)
+ *   RaytracerInner::debug_render   (src/raytracer.rs:353-391)
+ *   Scene::new / BVH::build        (src/scene/mod.rs:82-106)
+ * INTEGRATION.md shows the Rust side.  All functions return 0 on success or an RT_ERR_* code and
+ * never unwind; rt_last_error() gives the text for the calling thread.
+ * Plain pointers and sizes only.  Citations are path:line under the reference tree.
+ */
+#ifndef RUSTRACER_HIP_H
+#define RUSTRACER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    RT_OK = 0,
+    RT_ERR_INVALID = 1,      /* bad argument (null pointer, zero size, index out of range) */
+    RT_ERR_UNSUPPORTED = 2,  /* reference `unimplemented!()`: triangle lights (src/scene/objects.rs:98-100) */
+    RT_ERR_HIP = 3,          /* a HIP runtime call failed (text in rt_last_error) */
+    RT_ERR_INTERRUPTED = 4,  /* *interrupt became non-zero (src/raytracer.rs:184,199,204) */
+    RT_ERR_LIMIT = 5         /* BVH deeper than the traversal stack, image larger than 2^31 pixels */
+};
+
+enum { RT_BSDF_DIFFUSE = 0, RT_BSDF_SPECULAR = 1 };          /* src/scene/objects.rs:10-13 */
+enum { RT_MODE_DEBUG = 0, RT_MODE_FULL = 1 };                /* src/raytracer.rs:151-154 */
+enum { RT_DIRECT_IMPORTANCE = 0, RT_DIRECT_HEMISPHERE = 1 }; /* src/raytracer.rs:251-286; hemisphere: README.md:9 */
+
+/* Material (src/scene/objects.rs:16-20), 32 bytes. */
+typedef struct rt_material {
+    uint32_t bsdf;
+    float reflectance[3];
+    float emittance[3];
+    uint32_t pad;
+} rt_material;
+
+/* Everything do_render reads from RenderConfig + ScreenParams + camera (src/raytracer.rs:88-134,
+ * 174-177), plus the deterministic seed and the screen-tile shard this call renders. */
+typedef struct rt_render_params {
+    uint32_t width, height;
+    float inv_w, inv_h, start, total, aspect_ratio, z;   /* ScreenParams, src/raytracer.rs:100-124 */
+    float cam[3];                                        /* camera_position, src/raytracer.rs:73 */
+    uint32_t spp, light_samples, bounces;                /* src/raytracer.rs:92-94 */
+    uint32_t mode;                                       /* RT_MODE_* */
+    uint32_t direct_estimator;                           /* RT_DIRECT_* */
+    uint64_t seed;                                       /* per-(pixel,sample) stream = hash(seed, y*width+x, sample) */
+    uint32_t tile_w, tile_h, shard_index, shard_count;   /* tile t = (y/tile_h)*tiles_x + x/tile_w belongs to shard t % shard_count */
+} rt_render_params;
+
+typedef struct rt_scene_info {
+    uint32_t n_tri, n_sph, n_mat, n_lights;
+    uint32_t n_inner_nodes;   /* device BVH: inner nodes only, 64 B each; leaves are child references */
+    uint32_t bvh_depth;       /* inner levels on the longest root-to-leaf chain */
+    uint64_t device_bytes;    /* flattened scene bytes resident in HBM */
+} rt_scene_info;
+
+/* Work counters of the last render / cast on this scene.  A ray is one
+ * Scene::intersect (src/scene/mod.rs:406) or Scene::is_occluded (src/scene/mod.rs:452) call. */
+typedef struct rt_counters {
+    uint64_t rays_closest;    /* intersect calls */
+    uint64_t rays_shadow;     /* is_occluded calls */
+    uint64_t samples;         /* camera samples = owned pixels * spp */
+    uint64_t inner_nodes;     /* inner nodes fetched           (filled only when stats are enabled) */
+    uint64_t tris_tested;     /* ray-triangle tests            (stats) */
+    uint64_t sphs_tested;     /* ray-sphere tests              (stats) */
+    uint64_t closest_hits_tri, closest_hits_sph; /* shaded vertices by primitive type (stats) */
+    double   kernel_ms_closest, kernel_ms_shadow, kernel_ms_shade;  /* HIP-event time per kernel class (timing enabled) */
+    uint64_t launches_closest, launches_shadow;
+} rt_counters;
+
+typedef struct rt_scene rt_scene;
+
+const char* rt_last_error(void);
+/* Binds the calling process to one GPU (hipSetDevice).  One process per GPU. */
+int rt_init(int device);
+
+/* Scene::new (src/scene/mod.rs:82-106): objects = triangles then spheres, lights = objects with
+ * non-black emittance, then the BVH (bvh 0.3.2 BVH::build restated) is built on the host, flattened
+ * to device buffers and uploaded.  tri_pos/tri_nrm: 9 floats per triangle (p1,p2,p3 / vn1,vn2,vn3 as
+ * Triangle stores them, src/scene/objects.rs:185-195); sph: (center, radius).  Inputs are copied. */
+int rt_scene_create(const float* tri_pos, const float* tri_nrm, const uint32_t* tri_mat, uint32_t n_tri,
+                    const float* sph, const uint32_t* sph_mat, uint32_t n_sph,
+                    const rt_material* mats, uint32_t n_mat, rt_scene** out);
+void rt_scene_destroy(rt_scene* scene);
+int rt_scene_info_get(const rt_scene* scene, rt_scene_info* out);
+/* Light object indices (Scene::light_indexes, src/scene/mod.rs:495). */
+int rt_scene_lights(const rt_scene* scene, uint32_t* out, uint32_t capacity);
+/* Host copy of the flattened BVH for inspection: per inner node 16 words
+ * {l_min[3], l_max[3], r_min[3], r_max[3], left, right, 0, 0}; child bit 31 set = leaf(object index).
+ * rank[object] = position of the object's leaf in the reference's DFS (right child first). */
+int rt_scene_bvh(const rt_scene* scene, uint32_t* node_words, uint32_t* rank);
+
+/* do_render / debug_render (src/raytracer.rs:167, 353) for the pixels of one shard.
+ * rgba: width*height*4 bytes, row-major, top row first, alpha 255 (SharedPixelBuffer,
+ * src/raytracer.rs:22-51); only owned pixels are written.
+ * rt_render: rgba is host memory; blocks; progress (0..100, src/raytracer.rs:79) and interrupt may be NULL.
+ * rt_render_device: rgba is device memory; work is enqueued on `stream` (hipStream_t, may be NULL)
+ * and the call returns without synchronising. */
+int rt_render(rt_scene* scene, const rt_render_params* params, uint8_t* rgba,
+              volatile uint32_t* progress, const volatile uint32_t* interrupt);
+int rt_render_device(rt_scene* scene, const rt_render_params* params, void* rgba_dev, void* stream);
+
+/* Primary-ray cast only (BASELINE config 3): object index of the winning leaf
+ * (shape_index, src/scene/mod.rs:434-439; 0xFFFFFFFF = miss) and its distance, per owned pixel. */
+int rt_cast_primary(rt_scene* scene, const rt_render_params* params, uint32_t* ids, float* t);
+int rt_cast_primary_device(rt_scene* scene, const rt_render_params* params, void* ids_dev, void* t_dev, void* stream);
+
+/* Arbitrary rays (host arrays, 3 floats each): Scene::intersect and Scene::is_occluded. */
+int rt_intersect_rays(rt_scene* scene, const float* origins, const float* directions, uint32_t n, uint32_t* ids, float* t);
+int rt_occluded_rays(rt_scene* scene, const float* origins, const float* directions, const float* max_dist, uint32_t n, uint8_t* out);
+
+int rt_get_counters(const rt_scene* scene, rt_counters* out);
+/* Options: "stats" (0/1 traversal counters), "timing" (0/1 HIP-event kernel timing),
+ * "max_paths" (paths in flight per pass). */
+int rt_set_option(rt_scene* scene, const char* name, uint64_t value);
+
+/* Screen tiles (no reference counterpart): pack the owned tiles of a frame into a
+ * compact buffer of n_owned_tiles(padded) * tile_w*tile_h*bytes_per_pixel and back.  Device pointers. */
+uint32_t rt_tiles_per_shard(const rt_render_params* params);   /* ceil(n_tiles / shard_count): equal for every shard */
+int rt_tiles_pack(const rt_render_params* params, const void* frame_dev, void* compact_dev, uint32_t bytes_per_pixel, void* stream);
+int rt_tiles_unpack(const rt_render_params* params, uint32_t shard_index, const void* compact_dev, void* frame_dev,
+                    uint32_t bytes_per_pixel, void* stream);
+
+/* ---- host-side helpers mirroring the reference's scene constructors ---- */
+/* ScreenParams::from_config (src/raytracer.rs:110-124); fills width..z of *params. */
+void rt_screen_params(uint32_t width, uint32_t height, float fov_radians, rt_render_params* params);
+/* Scene::new_dragon/new_teapot/new_specular/new_diffuse/new_triangle (src/scene/mod.rs:108-401),
+ * plus "sphere_on_plane" and "specular_teapot" (BASELINE configs 1 and 5).  obj_path replaces the
+ * reference's hard-coded "obj/teapot.obj" / "obj/dragon.obj" (src/scene/mod.rs:202, 240). */
+int rt_scene_new_named(const char* name, const char* obj_path, rt_scene** out);
+/* new_dragon with the mesh given as arrays (3 floats per vertex, 3 indices per face) instead of a file. */
+int rt_scene_new_dragon_mesh(const float* vpos, const float* vnrm, uint32_t n_vert, const uint32_t* faces, uint32_t n_face, rt_scene** out);
+/* The object list Scene::new received, in the rt_scene_create layout (arrays sized from rt_scene_info). */
+int rt_scene_export(const rt_scene* scene, float* tri_pos, float* tri_nrm, uint32_t* tri_mat, float* sph, uint32_t* sph_mat, rt_material* mats);
+/* Deterministic procedural dragon-class stand-in for the missing obj/dragon.obj: a displaced torus-knot
+ * tube, nu*nv vertices, 2*nu*nv triangles.  vpos/vnrm: nu*nv*3 floats; faces: 2*nu*nv*3 indices. */
+int rt_make_dragon_standin(uint32_t nu, uint32_t nv, float* vpos, float* vnrm, uint32_t* faces);
+
+/* ---- debug probes used by the parity tests (device evaluation of the shared arithmetic) ---- */
+/* op: 0 sin, 1 cos, 2 acos, 3 pow(x, y[i]), 4 to_color -> out as float */
+int rt_debug_math(uint32_t op, const float* x, const float* y, uint32_t n, float* out);
+int rt_debug_rng(uint64_t seed, uint32_t pixel_index, uint32_t sample, uint32_t n, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,187 @@
+"""ctypes binding for the CPU oracle (oracle/liboracle_rt.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg.  Nothing under rustracer_amd/ may import this module.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class RenderParams(C.Structure):
+    """Byte-for-byte the rt_render_params of include/rustracer_hip.h."""
+    _fields_ = [
+        ("width", C.c_uint32), ("height", C.c_uint32),
+        ("inv_w", C.c_float), ("inv_h", C.c_float), ("start", C.c_float), ("total", C.c_float),
+        ("aspect_ratio", C.c_float), ("z", C.c_float),
+        ("cam", C.c_float * 3),
+        ("spp", C.c_uint32), ("light_samples", C.c_uint32), ("bounces", C.c_uint32),
+        ("mode", C.c_uint32), ("direct_estimator", C.c_uint32),
+        ("seed", C.c_uint64),
+        ("tile_w", C.c_uint32), ("tile_h", C.c_uint32), ("shard_index", C.c_uint32), ("shard_count", C.c_uint32),
+    ]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle_rt.so")
+        if not os.path.exists(path):
+            raise RuntimeError("oracle/liboracle_rt.so missing: run `make -C oracle` (or __graft_entry__.build())")
+        L = C.CDLL(path)
+        L.orc_last_error.restype = C.c_char_p
+        for name in ("orc_scene_create", "orc_scene_new_named", "orc_scene_new_dragon_mesh"):
+            getattr(L, name).restype = C.c_void_p
+        L.orc_scene_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
+                                       C.c_void_p, C.c_uint32]
+        L.orc_scene_new_named.argtypes = [C.c_char_p, C.c_char_p]
+        L.orc_scene_new_dragon_mesh.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+        L.orc_scene_destroy.argtypes = [C.c_void_p]
+        L.orc_scene_counts.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+        L.orc_scene_export.argtypes = [C.c_void_p] + [C.c_void_p] * 7
+        L.orc_scene_bvh.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_screen_params.argtypes = [C.c_uint32, C.c_uint32, C.c_float, C.c_void_p]
+        L.orc_screen_to_world.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_render.restype = C.c_int
+        L.orc_cast_primary.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_cast_primary.restype = C.c_int
+        L.orc_intersect_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_occluded_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_tri_intersect.argtypes = [C.c_void_p] * 4
+        L.orc_tri_intersect.restype = C.c_int
+        L.orc_sphere_intersect.argtypes = [C.c_void_p] * 4
+        L.orc_sphere_intersect.restype = C.c_int
+        L.orc_tri_normal.argtypes = [C.c_void_p] * 4
+        L.orc_to_color.argtypes = [C.c_float]
+        L.orc_to_color.restype = C.c_uint8
+        L.orc_rng_stream.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_rng_raw.argtypes = [C.c_uint64, C.c_uint32, C.c_void_p]
+        for name in ("orc_math_sin", "orc_math_cos", "orc_math_acos"):
+            getattr(L, name).argtypes = [C.c_float]
+            getattr(L, name).restype = C.c_float
+        L.orc_math_pow.argtypes = [C.c_float, C.c_float]
+        L.orc_math_pow.restype = C.c_float
+        L.orc_random_sphere.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_random_hemisphere.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_to_coord_space.argtypes = [C.c_void_p] * 3
+        L.orc_hardware_threads.restype = C.c_uint32
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def make_params(width, height, spp=4, light_samples=4, bounces=50, mode=1, seed=0x5EED, cam=(0.0, 0.0, 0.0),
+                fov_degrees=90.0, direct_estimator=0, tile=(32, 32), shard=(0, 1)):
+    p = RenderParams()
+    fov = np.float32(fov_degrees) * (np.float32(np.pi) / np.float32(180.0))   # f32::to_radians (main.rs:95)
+    lib().orc_screen_params(width, height, C.c_float(float(fov)), C.byref(p))
+    p.cam[0], p.cam[1], p.cam[2] = cam
+    p.spp, p.light_samples, p.bounces = spp, light_samples, bounces
+    p.mode, p.direct_estimator, p.seed = mode, direct_estimator, seed
+    p.tile_w, p.tile_h = tile
+    p.shard_index, p.shard_count = shard
+    return p
+
+
+class OracleScene:
+    def __init__(self, handle):
+        if not handle:
+            raise RuntimeError("oracle scene: " + lib().orc_last_error().decode())
+        self.h = C.c_void_p(handle)
+        c = [C.c_uint32() for _ in range(5)]
+        lib().orc_scene_counts(self.h, *[C.byref(x) for x in c])
+        self.T, self.S, self.M, self.nlights, self.nnodes = [x.value for x in c]
+
+    @classmethod
+    def named(cls, name, obj_path=None):
+        return cls(lib().orc_scene_new_named(name.encode(), obj_path.encode() if obj_path else None))
+
+    @classmethod
+    def dragon_mesh(cls, vpos, vnrm, faces):
+        vpos = np.ascontiguousarray(vpos, np.float32)
+        vnrm = np.ascontiguousarray(vnrm, np.float32) if vnrm is not None else None
+        faces = np.ascontiguousarray(faces, np.uint32)
+        return cls(lib().orc_scene_new_dragon_mesh(_p(vpos), _p(vnrm), vpos.shape[0], _p(faces), faces.shape[0]))
+
+    @classmethod
+    def raw(cls, tri_pos, tri_nrm, tri_mat, sph, sph_mat, mats):
+        tri_pos = np.ascontiguousarray(tri_pos, np.float32).reshape(-1, 9)
+        tri_nrm = np.ascontiguousarray(tri_nrm, np.float32).reshape(-1, 9)
+        tri_mat = np.ascontiguousarray(tri_mat, np.uint32)
+        sph = np.ascontiguousarray(sph, np.float32).reshape(-1, 4)
+        sph_mat = np.ascontiguousarray(sph_mat, np.uint32)
+        mats = np.ascontiguousarray(mats).view(np.uint32).reshape(-1, 8)
+        return cls(lib().orc_scene_create(_p(tri_pos), _p(tri_nrm), _p(tri_mat), tri_pos.shape[0], _p(sph), _p(sph_mat),
+                                          sph.shape[0], _p(mats), mats.shape[0]))
+
+    def export(self):
+        """Object list in the raw rt_scene_create layout."""
+        tri_pos = np.zeros((self.T, 9), np.float32)
+        tri_nrm = np.zeros((self.T, 9), np.float32)
+        tri_mat = np.zeros(self.T, np.uint32)
+        sph = np.zeros((self.S, 4), np.float32)
+        sph_mat = np.zeros(self.S, np.uint32)
+        mats = np.zeros((self.M, 8), np.uint32)
+        lights = np.zeros(self.nlights, np.uint32)
+        lib().orc_scene_export(self.h, _p(tri_pos), _p(tri_nrm), _p(tri_mat), _p(sph), _p(sph_mat), _p(mats), _p(lights))
+        return dict(tri_pos=tri_pos, tri_nrm=tri_nrm, tri_mat=tri_mat, sph=sph, sph_mat=sph_mat, mats=mats, lights=lights)
+
+    def bvh(self):
+        w = np.zeros((self.nnodes, 16), np.uint32)
+        lib().orc_scene_bvh(self.h, _p(w))
+        return w
+
+    def render(self, params, nthreads=0, want_radiance=False):
+        rgba = np.zeros((params.height, params.width, 4), np.uint8)
+        rad = np.zeros((params.height, params.width, 3), np.float32) if want_radiance else None
+        cnt = np.zeros(4, np.uint64)
+        rc = lib().orc_render(self.h, C.byref(params), _p(rgba), _p(rad), nthreads, _p(cnt))
+        if rc != 0:
+            raise RuntimeError("orc_render: " + lib().orc_last_error().decode())
+        out = dict(rgba=rgba, intersect_calls=int(cnt[0]), occluded_calls=int(cnt[1]), nodes_visited=int(cnt[2]),
+                   prims_tested=int(cnt[3]))
+        if want_radiance:
+            out["radiance"] = rad
+        return out
+
+    def cast_primary(self, params, nthreads=0):
+        ids = np.full((params.height, params.width), 0xFFFFFFFF, np.uint32)
+        ts = np.full((params.height, params.width), np.inf, np.float32)
+        cnt = np.zeros(4, np.uint64)
+        lib().orc_cast_primary(self.h, C.byref(params), _p(ids), _p(ts), nthreads, _p(cnt))
+        return ids, ts, cnt
+
+    def intersect_rays(self, org, dirs):
+        org = np.ascontiguousarray(org, np.float32).reshape(-1, 3)
+        dirs = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        ids = np.zeros(org.shape[0], np.uint32)
+        ts = np.zeros(org.shape[0], np.float32)
+        lib().orc_intersect_rays(self.h, _p(org), _p(dirs), org.shape[0], _p(ids), _p(ts))
+        return ids, ts
+
+    def occluded_rays(self, org, dirs, maxd):
+        org = np.ascontiguousarray(org, np.float32).reshape(-1, 3)
+        dirs = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        maxd = np.ascontiguousarray(maxd, np.float32)
+        out = np.zeros(org.shape[0], np.uint8)
+        lib().orc_occluded_rays(self.h, _p(org), _p(dirs), _p(maxd), org.shape[0], _p(out))
+        return out
+
+    def close(self):
+        if self.h:
+            lib().orc_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,753 @@
+// rt_api.hip — implementation of the C ABI in include/rustracer_hip.h: scene upload, pass
+// scheduling of the wavefront kernels (rt_kernels.h) and the debug probes.  gfx950 only.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/rustracer_hip.h"
+#include "host_scene.h"
+#include "rt_kernels.h"
+
+using namespace rt;
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string& msg) {
+    g_error = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                       \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess) return fail(RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;   // elements
+    int ensure(size_t n) {
+        if (n <= cap) return RT_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        HIP_TRY(hipMalloc((void**)&p, n * sizeof(T)));
+        cap = n;
+        return RT_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct EventPair {
+    hipEvent_t a, b;
+    int cls;   // 0 closest, 1 shadow, 2 shade/other
+};
+
+}  // namespace
+
+struct rt_scene {
+    HostScene host;
+    FlatBVH bvh;
+    std::vector<uint32_t> lights;
+    bool has_triangle_light = false;
+    bool uploaded = false;
+
+    DevBuf<float4> d_nodes, d_tris, d_tri_nrm, d_sph, d_mats;
+    DevBuf<uint2> d_sph_aux;
+    DevBuf<uint32_t> d_lights, d_ovf;
+    DevScene dev;
+    uint64_t device_bytes = 0;
+
+    // workspace (grow-only; no allocation in steady state)
+    DevBuf<uint32_t> w_counts, w_hit_id;
+    DevBuf<float> w_hit_t;
+    DevBuf<float4> w_ray_o[2], w_ray_d[2], w_vP, w_vN, w_contrib, w_stackA, w_stackB, w_radiance, w_accum;
+    DevBuf<uint64_t> w_rng;
+    DevBuf<ulonglong2> w_jump;
+    uint32_t jump_nlL = 0xFFFFFFFFu;
+    DevBuf<unsigned long long> w_stats;
+    DevBuf<uint8_t> w_frame;
+    DevBuf<uint32_t> w_ids;
+    DevBuf<float> w_ts;
+    DevBuf<float> w_rays;   // scratch for arbitrary-ray calls
+
+    bool opt_stats = false, opt_timing = false;
+    uint64_t opt_max_paths = 1ull << 22;
+    uint32_t grid_max = 2048;
+
+    std::vector<EventPair> events;
+    size_t events_used = 0;
+    uint64_t samples = 0;
+    uint64_t launches[3] = {0, 0, 0};
+};
+
+namespace {
+
+uint32_t grid_for(const rt_scene* s, uint64_t n) {
+    uint64_t g = (n + RT_BLOCK - 1) / RT_BLOCK;
+    if (g < 1) g = 1;
+    if (g > s->grid_max) g = s->grid_max;
+    return (uint32_t)g;
+}
+
+// Host half of Scene::new: the BVH and the light list (src/scene/mod.rs:91-99).  No GPU needed.
+void prepare_host(rt_scene* s) {
+    const HostScene& h = s->host;
+    const uint32_t T = h.n_tri(), S = h.n_sph();
+    build_bvh(h, &s->bvh);
+    s->lights.clear();
+    s->has_triangle_light = false;
+    for (uint32_t i = 0; i < T; ++i)
+        if (!scene_is_black(h.mats[h.tri_mat[i]].emittance)) { s->lights.push_back(i); s->has_triangle_light = true; }
+    for (uint32_t i = 0; i < S; ++i)
+        if (!scene_is_black(h.mats[h.sph_mat[i]].emittance)) s->lights.push_back(T + i);
+    s->device_bytes = (uint64_t)s->bvh.n_inner() * 64 + (uint64_t)T * 96 + (uint64_t)S * 24 + (uint64_t)h.mats.size() * 32 + s->lights.size() * 4;
+}
+
+// Device half: flatten to the kernel layout and upload, on first use.
+int upload_scene(rt_scene* s) {
+    if (s->uploaded) return RT_OK;
+    const HostScene& h = s->host;
+    const uint32_t T = h.n_tri(), S = h.n_sph(), M = (uint32_t)h.mats.size();
+    const FlatBVH& b = s->bvh;
+
+    int dev_id = 0;
+    HIP_TRY(hipGetDevice(&dev_id));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev_id));
+    s->grid_max = (uint32_t)prop.multiProcessorCount * 8u;
+    if (s->grid_max == 0) s->grid_max = 2048;
+
+    const uint32_t ovf_rows = b.depth > RT_STACK_LDS ? b.depth - RT_STACK_LDS : 0;
+    if (ovf_rows > 224) return fail(RT_ERR_LIMIT, "BVH deeper than 256 levels");
+
+    std::vector<float4> tris(3 * (size_t)T), nrm(3 * (size_t)T), sph(S ? S : 1), mats(2 * (size_t)(M ? M : 1));
+    std::vector<uint2> aux(S ? S : 1);
+    for (uint32_t i = 0; i < T; ++i) {
+        const float* p = &h.tri_pos[9 * (size_t)i];
+        const float* n = &h.tri_nrm[9 * (size_t)i];
+        const vec3 p1 = mk(p[0], p[1], p[2]), p2 = mk(p[3], p[4], p[5]), p3 = mk(p[6], p[7], p[8]);
+        const vec3 e1 = sub(p2, p1), e2 = sub(p3, p1);
+        const rt_material& m = h.mats[h.tri_mat[i]];
+        const bool emissive = !scene_is_black(m.emittance);
+        const uint32_t info = h.tri_mat[i] | (emissive ? 0u : RT_INFO_BLOCKER);
+        tris[3 * (size_t)i] = make_float4(p1.x, p1.y, p1.z, bits_to_float(b.rank[i]));
+        tris[3 * (size_t)i + 1] = make_float4(e1.x, e1.y, e1.z, bits_to_float(info));
+        tris[3 * (size_t)i + 2] = make_float4(e2.x, e2.y, e2.z, 0.0f);
+        for (int k = 0; k < 3; ++k) nrm[3 * (size_t)i + k] = make_float4(n[3 * k], n[3 * k + 1], n[3 * k + 2], 0.0f);
+    }
+    for (uint32_t i = 0; i < S; ++i) {
+        const float* c = &h.sph[4 * (size_t)i];
+        const rt_material& m = h.mats[h.sph_mat[i]];
+        const bool emissive = !scene_is_black(m.emittance);
+        sph[i] = make_float4(c[0], c[1], c[2], c[3]);
+        aux[i] = make_uint2(b.rank[T + i], h.sph_mat[i] | (emissive ? 0u : RT_INFO_BLOCKER));
+    }
+    for (uint32_t i = 0; i < M; ++i) {
+        const rt_material& m = h.mats[i];
+        mats[2 * (size_t)i] = make_float4(bits_to_float(m.bsdf), m.reflectance[0], m.reflectance[1], m.reflectance[2]);
+        mats[2 * (size_t)i + 1] = make_float4(m.emittance[0], m.emittance[1], m.emittance[2], 0.0f);
+    }
+    const size_t n_inner = b.n_inner();
+    int rc;
+    if ((rc = s->d_nodes.ensure(4 * (n_inner ? n_inner : 1)))) return rc;
+    if ((rc = s->d_tris.ensure(tris.size() ? tris.size() : 1))) return rc;
+    if ((rc = s->d_tri_nrm.ensure(nrm.size() ? nrm.size() : 1))) return rc;
+    if ((rc = s->d_sph.ensure(sph.size()))) return rc;
+    if ((rc = s->d_sph_aux.ensure(aux.size()))) return rc;
+    if ((rc = s->d_mats.ensure(mats.size()))) return rc;
+    if ((rc = s->d_lights.ensure(s->lights.size() ? s->lights.size() : 1))) return rc;
+    if (ovf_rows && (rc = s->d_ovf.ensure((size_t)ovf_rows * s->grid_max * RT_BLOCK))) return rc;
+    if (n_inner) HIP_TRY(hipMemcpy(s->d_nodes.p, b.words.data(), n_inner * 64, hipMemcpyHostToDevice));
+    if (T) {
+        HIP_TRY(hipMemcpy(s->d_tris.p, tris.data(), tris.size() * sizeof(float4), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(s->d_tri_nrm.p, nrm.data(), nrm.size() * sizeof(float4), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMemcpy(s->d_sph.p, sph.data(), sph.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_sph_aux.p, aux.data(), aux.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_mats.p, mats.data(), mats.size() * sizeof(float4), hipMemcpyHostToDevice));
+    if (!s->lights.empty())
+        HIP_TRY(hipMemcpy(s->d_lights.p, s->lights.data(), s->lights.size() * 4, hipMemcpyHostToDevice));
+    DevScene& d = s->dev;
+    d.nodes = s->d_nodes.p; d.tris = s->d_tris.p; d.tri_nrm = s->d_tri_nrm.p; d.sph = s->d_sph.p; d.sph_aux = s->d_sph_aux.p;
+    d.mats = s->d_mats.p; d.lights = s->d_lights.p;
+    d.n_tri = T; d.n_sph = S; d.n_lights = (uint32_t)s->lights.size(); d.root = b.root;
+    d.ovf = s->d_ovf.p; d.ovf_stride = s->grid_max * RT_BLOCK;
+    if ((rc = s->w_stats.ensure(ST_COUNT))) return rc;
+    HIP_TRY(hipMemset(s->w_stats.p, 0, ST_COUNT * sizeof(unsigned long long)));
+    s->uploaded = true;
+    return RT_OK;
+}
+
+int validate_params(const rt_render_params* P) {
+    if (!P) return fail(RT_ERR_INVALID, "params is NULL");
+    if (P->width == 0 || P->height == 0) return fail(RT_ERR_INVALID, "width and height must be > 0");
+    if ((uint64_t)P->width * P->height >= (1ull << 31)) return fail(RT_ERR_LIMIT, "image larger than 2^31 pixels");
+    if (P->tile_w == 0 || P->tile_h == 0 || P->shard_count == 0 || P->shard_index >= P->shard_count)
+        return fail(RT_ERR_INVALID, "bad tile/shard description");
+    if (P->mode > RT_MODE_FULL || P->direct_estimator > RT_DIRECT_HEMISPHERE) return fail(RT_ERR_INVALID, "bad mode or estimator");
+    return RT_OK;
+}
+
+struct Shard {
+    uint32_t tiles_x, n_tiles, n_own_tiles;
+    uint64_t n_own_pix;
+};
+Shard shard_of(const rt_render_params& P) {
+    Shard s;
+    s.tiles_x = (P.width + P.tile_w - 1) / P.tile_w;
+    const uint32_t tiles_y = (P.height + P.tile_h - 1) / P.tile_h;
+    s.n_tiles = s.tiles_x * tiles_y;
+    s.n_own_tiles = s.n_tiles > P.shard_index ? (s.n_tiles - P.shard_index + P.shard_count - 1) / P.shard_count : 0;
+    s.n_own_pix = (uint64_t)s.n_own_tiles * P.tile_w * P.tile_h;
+    return s;
+}
+
+void begin_timing(rt_scene* s, hipStream_t stream, int cls, size_t* idx) {
+    *idx = (size_t)-1;
+    s->launches[cls]++;
+    if (!s->opt_timing) return;
+    if (s->events_used == s->events.size()) {
+        EventPair ep;
+        if (hipEventCreate(&ep.a) != hipSuccess || hipEventCreate(&ep.b) != hipSuccess) return;
+        s->events.push_back(ep);
+    }
+    *idx = s->events_used++;
+    s->events[*idx].cls = cls;
+    (void)hipEventRecord(s->events[*idx].a, stream);
+}
+void end_timing(rt_scene* s, hipStream_t stream, size_t idx) {
+    if (idx == (size_t)-1) return;
+    (void)hipEventRecord(s->events[idx].b, stream);
+}
+
+void reset_counters(rt_scene* s, hipStream_t stream) {
+    (void)hipMemsetAsync(s->w_stats.p, 0, ST_COUNT * sizeof(unsigned long long), stream);
+    s->events_used = 0;
+    s->samples = 0;
+    s->launches[0] = s->launches[1] = s->launches[2] = 0;
+}
+
+int ensure_jump(rt_scene* s, uint32_t nlL, hipStream_t stream) {
+    if (s->jump_nlL == nlL) return RT_OK;
+    std::vector<ulonglong2> j((size_t)nlL + 1);
+    // draw 2*i of the vertex: state_i = A_i * state + C_i for the LCG of fastrand 1.4.0
+    unsigned long long A = 1, C = 0;
+    for (uint32_t i = 0; i <= nlL; ++i) {
+        j[i].x = A; j[i].y = C;
+        for (int k = 0; k < 2; ++k) { A = A * RT_PCG_MUL; C = C * RT_PCG_MUL + RT_PCG_INC; }
+    }
+    int rc;
+    if ((rc = s->w_jump.ensure(j.size()))) return rc;
+    HIP_TRY(hipStreamSynchronize(stream));   // the previous table may still be in use
+    HIP_TRY(hipMemcpy(s->w_jump.p, j.data(), j.size() * sizeof(ulonglong2), hipMemcpyHostToDevice));
+    s->jump_nlL = nlL;
+    return RT_OK;
+}
+
+int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, hipStream_t stream, volatile uint32_t* progress,
+                const volatile uint32_t* interrupt) {
+    int rc;
+    if ((rc = validate_params(params))) return rc;
+    if (!rgba_dev) return fail(RT_ERR_INVALID, "rgba is NULL");
+    if ((rc = upload_scene(s))) return rc;
+    const rt_render_params& P = *params;
+    const Shard sh = shard_of(P);
+    reset_counters(s, stream);
+    if (progress) *progress = 0;
+    if (sh.n_own_pix == 0) { if (progress) *progress = 100; return RT_OK; }
+    if (sh.n_own_pix >= (1ull << 31)) return fail(RT_ERR_LIMIT, "shard larger than 2^31 pixels");
+
+    if (P.mode == RT_MODE_DEBUG) {
+        size_t ev;
+        begin_timing(s, stream, 0, &ev);
+        const uint32_t g = grid_for(s, sh.n_own_pix);
+        if (s->opt_stats)
+            hipLaunchKernelGGL(k_primary<true>, dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, P, sh.tiles_x, (uint32_t)sh.n_own_pix,
+                               (uint32_t*)nullptr, (float*)nullptr, rgba_dev, s->w_stats.p);
+        else
+            hipLaunchKernelGGL(k_primary<false>, dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, P, sh.tiles_x, (uint32_t)sh.n_own_pix,
+                               (uint32_t*)nullptr, (float*)nullptr, rgba_dev, s->w_stats.p);
+        end_timing(s, stream, ev);
+        HIP_TRY(hipGetLastError());
+        if (progress) { HIP_TRY(hipStreamSynchronize(stream)); *progress = 100; }
+        return RT_OK;
+    }
+
+    if (P.spp == 0 || P.light_samples == 0) return fail(RT_ERR_INVALID, "spp and light_samples must be > 0");
+    const bool hemi = P.direct_estimator == RT_DIRECT_HEMISPHERE;
+    if (!hemi && s->has_triangle_light && P.bounces >= 1)
+        return fail(RT_ERR_UNSUPPORTED, "triangle lights: Object::sample_l is unimplemented in the reference (objects.rs:98-100)");
+    const uint32_t n_groups = hemi ? 1u : s->dev.n_lights;
+    const uint64_t nlL64 = (uint64_t)n_groups * P.light_samples;
+    if (nlL64 >= (1ull << 24)) return fail(RT_ERR_LIMIT, "lights * light_samples too large");
+    const uint32_t nlL = (uint32_t)nlL64;
+
+    uint64_t max_paths = s->opt_max_paths;
+    const uint64_t cap_by_rays = (1ull << 30) / (nlL ? nlL : 1);
+    if (max_paths > cap_by_rays) max_paths = cap_by_rays;
+    if (max_paths < 64) max_paths = 64;
+    uint32_t npix_chunk, spc;
+    if (sh.n_own_pix <= max_paths) {
+        npix_chunk = (uint32_t)sh.n_own_pix;
+        uint64_t k = max_paths / sh.n_own_pix;
+        spc = (uint32_t)(k < P.spp ? k : P.spp);
+    } else {
+        npix_chunk = (uint32_t)max_paths;
+        spc = 1;
+    }
+    const uint64_t cap_paths = (uint64_t)npix_chunk * spc;
+    const uint32_t levels = P.bounces + 1;
+
+    if ((rc = s->w_counts.ensure(levels + 1))) return rc;
+    for (int q = 0; q < 2; ++q) {
+        if ((rc = s->w_ray_o[q].ensure(cap_paths))) return rc;
+        if ((rc = s->w_ray_d[q].ensure(cap_paths))) return rc;
+    }
+    if ((rc = s->w_hit_id.ensure(cap_paths))) return rc;
+    if ((rc = s->w_hit_t.ensure(cap_paths))) return rc;
+    if ((rc = s->w_vP.ensure(cap_paths))) return rc;
+    if ((rc = s->w_vN.ensure(cap_paths))) return rc;
+    if ((rc = s->w_rng.ensure(cap_paths))) return rc;
+    if ((rc = s->w_contrib.ensure(cap_paths * (nlL ? nlL : 1)))) return rc;
+    if ((rc = s->w_stackA.ensure(cap_paths * (P.bounces ? P.bounces : 1)))) return rc;
+    if ((rc = s->w_stackB.ensure(cap_paths * (P.bounces ? P.bounces : 1)))) return rc;
+    if ((rc = s->w_radiance.ensure(cap_paths))) return rc;
+    if ((rc = s->w_accum.ensure(sh.n_own_pix))) return rc;
+    if ((rc = ensure_jump(s, nlL, stream))) return rc;
+
+    PassCtx pc;
+    memset(&pc, 0, sizeof pc);
+    pc.P = P;
+    pc.seed_mixed = mix64(P.seed);
+    pc.tiles_x = sh.tiles_x; pc.n_tiles = sh.n_tiles;
+    pc.n_groups = n_groups; pc.nlL = nlL;
+    pc.counts = s->w_counts.p;
+    for (int q = 0; q < 2; ++q) { pc.ray_o[q] = s->w_ray_o[q].p; pc.ray_d[q] = s->w_ray_d[q].p; }
+    pc.hit_id = s->w_hit_id.p; pc.hit_t = s->w_hit_t.p;
+    pc.vP = s->w_vP.p; pc.vN = s->w_vN.p; pc.rng = s->w_rng.p; pc.contrib = s->w_contrib.p;
+    pc.stackA = s->w_stackA.p; pc.stackB = s->w_stackB.p; pc.radiance = s->w_radiance.p; pc.accum = s->w_accum.p;
+    pc.jump = s->w_jump.p; pc.stats = s->w_stats.p; pc.rgba = rgba_dev;
+
+    const uint64_t n_pix_chunks = (sh.n_own_pix + npix_chunk - 1) / npix_chunk;
+    const uint64_t n_s_chunks = (P.spp + spc - 1) / spc;
+    const uint64_t total_passes = n_pix_chunks * n_s_chunks;
+    uint64_t done = 0;
+    for (uint64_t pix0 = 0; pix0 < sh.n_own_pix; pix0 += npix_chunk) {
+        const uint32_t npix = (uint32_t)((sh.n_own_pix - pix0) < npix_chunk ? (sh.n_own_pix - pix0) : npix_chunk);
+        for (uint32_t s0 = 0; s0 < P.spp; s0 += spc) {
+            if (interrupt && *interrupt) {
+                HIP_TRY(hipStreamSynchronize(stream));
+                return fail(RT_ERR_INTERRUPTED, "render interrupted");
+            }
+            const uint32_t spc_now = (P.spp - s0) < spc ? (P.spp - s0) : spc;
+            pc.pix0 = (uint32_t)pix0; pc.npix = npix; pc.s0 = s0; pc.spc = spc_now; pc.npaths = npix * spc_now;
+            s->samples += 0;   // owned, valid samples are counted on the device side via ST_RAYS (primary level)
+            HIP_TRY(hipMemsetAsync(pc.counts, 0, (levels + 1) * sizeof(uint32_t), stream));
+            size_t ev;
+            begin_timing(s, stream, 2, &ev);
+            hipLaunchKernelGGL(k_generate, dim3(grid_for(s, pc.npaths)), dim3(RT_BLOCK), 0, stream, pc);
+            end_timing(s, stream, ev);
+            for (uint32_t level = 0; level < levels; ++level) {
+                const uint32_t g = grid_for(s, pc.npaths);
+                begin_timing(s, stream, 0, &ev);
+                if (s->opt_stats) hipLaunchKernelGGL(k_extend<true>, dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                else hipLaunchKernelGGL(k_extend<false>, dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                end_timing(s, stream, ev);
+                begin_timing(s, stream, 2, &ev);
+                hipLaunchKernelGGL(k_shade_a, dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                end_timing(s, stream, ev);
+                if (level == P.bounces) break;
+                if (nlL) {
+                    const uint32_t gs = grid_for(s, (uint64_t)pc.npaths * nlL);
+                    begin_timing(s, stream, hemi ? 0 : 1, &ev);
+                    if (hemi) {
+                        if (s->opt_stats) hipLaunchKernelGGL((k_shadow<true, true>), dim3(gs), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                        else hipLaunchKernelGGL((k_shadow<false, true>), dim3(gs), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                    } else {
+                        if (s->opt_stats) hipLaunchKernelGGL((k_shadow<true, false>), dim3(gs), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                        else hipLaunchKernelGGL((k_shadow<false, false>), dim3(gs), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                    }
+                    end_timing(s, stream, ev);
+                }
+                begin_timing(s, stream, 2, &ev);
+                hipLaunchKernelGGL(k_shade_b, dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                end_timing(s, stream, ev);
+            }
+            begin_timing(s, stream, 2, &ev);
+            hipLaunchKernelGGL(k_resolve, dim3(grid_for(s, pc.npix)), dim3(RT_BLOCK), 0, stream, pc);
+            end_timing(s, stream, ev);
+            HIP_TRY(hipGetLastError());
+            ++done;
+            if (progress || interrupt) {
+                HIP_TRY(hipStreamSynchronize(stream));
+                if (progress) *progress = (uint32_t)((float)done / (float)total_passes * 100.0f);   // raytracer.rs:191, 213
+            }
+        }
+    }
+    // samples = owned valid pixels * spp (host arithmetic; edge tiles are clipped)
+    {
+        uint64_t valid = 0;
+        for (uint32_t k = 0; k < sh.n_own_tiles; ++k) {
+            const uint32_t t = P.shard_index + k * P.shard_count;
+            const uint32_t x0 = (t % sh.tiles_x) * P.tile_w, y0 = (t / sh.tiles_x) * P.tile_h;
+            const uint32_t wv = x0 + P.tile_w <= P.width ? P.tile_w : (P.width > x0 ? P.width - x0 : 0);
+            const uint32_t hv = y0 + P.tile_h <= P.height ? P.tile_h : (P.height > y0 ? P.height - y0 : 0);
+            valid += (uint64_t)wv * hv;
+        }
+        s->samples = valid * P.spp;
+    }
+    if (progress) *progress = 100;
+    return RT_OK;
+}
+
+int cast_impl(rt_scene* s, const rt_render_params* params, uint32_t* ids_dev, float* t_dev, hipStream_t stream) {
+    int rc;
+    if ((rc = validate_params(params))) return rc;
+    if ((rc = upload_scene(s))) return rc;
+    const Shard sh = shard_of(*params);
+    reset_counters(s, stream);
+    if (sh.n_own_pix == 0) return RT_OK;
+    if (sh.n_own_pix >= (1ull << 31)) return fail(RT_ERR_LIMIT, "shard larger than 2^31 pixels");
+    const uint32_t g = grid_for(s, sh.n_own_pix);
+    size_t ev;
+    begin_timing(s, stream, 0, &ev);
+    if (s->opt_stats)
+        hipLaunchKernelGGL(k_primary<true>, dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, *params, sh.tiles_x, (uint32_t)sh.n_own_pix, ids_dev,
+                           t_dev, (uint8_t*)nullptr, s->w_stats.p);
+    else
+        hipLaunchKernelGGL(k_primary<false>, dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, *params, sh.tiles_x, (uint32_t)sh.n_own_pix, ids_dev,
+                           t_dev, (uint8_t*)nullptr, s->w_stats.p);
+    end_timing(s, stream, ev);
+    HIP_TRY(hipGetLastError());
+    // one closest-hit ray per valid owned pixel
+    uint64_t valid = 0;
+    for (uint32_t k = 0; k < sh.n_own_tiles; ++k) {
+        const uint32_t t = params->shard_index + k * params->shard_count;
+        const uint32_t x0 = (t % sh.tiles_x) * params->tile_w, y0 = (t / sh.tiles_x) * params->tile_h;
+        const uint32_t wv = x0 + params->tile_w <= params->width ? params->tile_w : (params->width > x0 ? params->width - x0 : 0);
+        const uint32_t hv = y0 + params->tile_h <= params->height ? params->tile_h : (params->height > y0 ? params->height - y0 : 0);
+        valid += (uint64_t)wv * hv;
+    }
+    s->samples = valid;
+    return RT_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+const char* rt_last_error(void) { return g_error.c_str(); }
+
+int rt_init(int device) {
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (n <= 0) return fail(RT_ERR_HIP, "no HIP device visible");
+    if (device < 0 || device >= n) return fail(RT_ERR_INVALID, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipFree(nullptr));
+    return RT_OK;
+}
+
+int rt_scene_create(const float* tri_pos, const float* tri_nrm, const uint32_t* tri_mat, uint32_t n_tri, const float* sph,
+                    const uint32_t* sph_mat, uint32_t n_sph, const rt_material* mats, uint32_t n_mat, rt_scene** out) {
+    if (!out) return fail(RT_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if ((n_tri && (!tri_pos || !tri_nrm || !tri_mat)) || (n_sph && (!sph || !sph_mat)) || ((n_tri || n_sph) && (!mats || !n_mat)))
+        return fail(RT_ERR_INVALID, "NULL array with a non-zero count");
+    if ((uint64_t)n_tri + n_sph >= (1ull << 31)) return fail(RT_ERR_LIMIT, "more than 2^31 objects");
+    for (uint32_t i = 0; i < n_tri; ++i)
+        if (tri_mat[i] >= n_mat) return fail(RT_ERR_INVALID, "triangle material index out of range");
+    for (uint32_t i = 0; i < n_sph; ++i)
+        if (sph_mat[i] >= n_mat) return fail(RT_ERR_INVALID, "sphere material index out of range");
+    for (uint32_t i = 0; i < n_mat; ++i)
+        if (mats[i].bsdf > RT_BSDF_SPECULAR) return fail(RT_ERR_INVALID, "unknown bsdf");
+    rt_scene* s = new rt_scene();
+    s->host.tri_pos.assign(tri_pos, tri_pos + 9 * (size_t)n_tri);
+    s->host.tri_nrm.assign(tri_nrm, tri_nrm + 9 * (size_t)n_tri);
+    s->host.tri_mat.assign(tri_mat, tri_mat + n_tri);
+    s->host.sph.assign(sph, sph + 4 * (size_t)n_sph);
+    s->host.sph_mat.assign(sph_mat, sph_mat + n_sph);
+    s->host.mats.assign(mats, mats + n_mat);
+    prepare_host(s);
+    *out = s;
+    return RT_OK;
+}
+
+void rt_scene_destroy(rt_scene* s) {
+    if (!s) return;
+    if (s->uploaded) (void)hipDeviceSynchronize();
+    s->d_nodes.release(); s->d_tris.release(); s->d_tri_nrm.release(); s->d_sph.release(); s->d_mats.release();
+    s->d_sph_aux.release(); s->d_lights.release(); s->d_ovf.release();
+    s->w_counts.release(); s->w_hit_id.release(); s->w_hit_t.release();
+    for (int q = 0; q < 2; ++q) { s->w_ray_o[q].release(); s->w_ray_d[q].release(); }
+    s->w_vP.release(); s->w_vN.release(); s->w_contrib.release(); s->w_stackA.release(); s->w_stackB.release();
+    s->w_radiance.release(); s->w_accum.release(); s->w_rng.release(); s->w_jump.release(); s->w_stats.release();
+    s->w_frame.release(); s->w_ids.release(); s->w_ts.release(); s->w_rays.release();
+    for (size_t i = 0; i < s->events.size(); ++i) { (void)hipEventDestroy(s->events[i].a); (void)hipEventDestroy(s->events[i].b); }
+    delete s;
+}
+
+int rt_scene_info_get(const rt_scene* s, rt_scene_info* out) {
+    if (!s || !out) return fail(RT_ERR_INVALID, "NULL argument");
+    out->n_tri = s->host.n_tri(); out->n_sph = s->host.n_sph(); out->n_mat = (uint32_t)s->host.mats.size();
+    out->n_lights = (uint32_t)s->lights.size();
+    out->n_inner_nodes = s->bvh.n_inner(); out->bvh_depth = s->bvh.depth; out->device_bytes = s->device_bytes;
+    return RT_OK;
+}
+
+int rt_scene_lights(const rt_scene* s, uint32_t* out, uint32_t capacity) {
+    if (!s || (!out && capacity)) return fail(RT_ERR_INVALID, "NULL argument");
+    for (uint32_t i = 0; i < capacity && i < s->lights.size(); ++i) out[i] = s->lights[i];
+    return RT_OK;
+}
+
+int rt_scene_bvh(const rt_scene* s, uint32_t* node_words, uint32_t* rank) {
+    if (!s) return fail(RT_ERR_INVALID, "NULL scene");
+    if (node_words && !s->bvh.words.empty()) memcpy(node_words, s->bvh.words.data(), s->bvh.words.size() * 4);
+    if (rank && !s->bvh.rank.empty()) memcpy(rank, s->bvh.rank.data(), s->bvh.rank.size() * 4);
+    return RT_OK;
+}
+
+int rt_render_device(rt_scene* s, const rt_render_params* params, void* rgba_dev, void* stream) {
+    if (!s) return fail(RT_ERR_INVALID, "NULL scene");
+    return render_impl(s, params, (uint8_t*)rgba_dev, (hipStream_t)stream, nullptr, nullptr);
+}
+
+int rt_render(rt_scene* s, const rt_render_params* params, uint8_t* rgba, volatile uint32_t* progress, const volatile uint32_t* interrupt) {
+    if (!s || !rgba) return fail(RT_ERR_INVALID, "NULL argument");
+    int rc;
+    if ((rc = validate_params(params))) return rc;
+    const size_t bytes = (size_t)params->width * params->height * 4;
+    if ((rc = s->w_frame.ensure(bytes))) return rc;
+    HIP_TRY(hipMemcpy(s->w_frame.p, rgba, bytes, hipMemcpyHostToDevice));
+    rc = render_impl(s, params, s->w_frame.p, nullptr, progress, interrupt);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(rgba, s->w_frame.p, bytes, hipMemcpyDeviceToHost));   // partial pixels stay in the buffer on interrupt
+    return rc;
+}
+
+int rt_cast_primary_device(rt_scene* s, const rt_render_params* params, void* ids_dev, void* t_dev, void* stream) {
+    if (!s) return fail(RT_ERR_INVALID, "NULL scene");
+    return cast_impl(s, params, (uint32_t*)ids_dev, (float*)t_dev, (hipStream_t)stream);
+}
+
+int rt_cast_primary(rt_scene* s, const rt_render_params* params, uint32_t* ids, float* t) {
+    if (!s || (!ids && !t)) return fail(RT_ERR_INVALID, "NULL argument");
+    int rc;
+    if ((rc = validate_params(params))) return rc;
+    const size_t n = (size_t)params->width * params->height;
+    if (ids) { if ((rc = s->w_ids.ensure(n))) return rc; HIP_TRY(hipMemcpy(s->w_ids.p, ids, n * 4, hipMemcpyHostToDevice)); }
+    if (t) { if ((rc = s->w_ts.ensure(n))) return rc; HIP_TRY(hipMemcpy(s->w_ts.p, t, n * 4, hipMemcpyHostToDevice)); }
+    rc = cast_impl(s, params, ids ? s->w_ids.p : nullptr, t ? s->w_ts.p : nullptr, nullptr);
+    HIP_TRY(hipDeviceSynchronize());
+    if (rc) return rc;
+    if (ids) HIP_TRY(hipMemcpy(ids, s->w_ids.p, n * 4, hipMemcpyDeviceToHost));
+    if (t) HIP_TRY(hipMemcpy(t, s->w_ts.p, n * 4, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_intersect_rays(rt_scene* s, const float* origins, const float* directions, uint32_t n, uint32_t* ids, float* t) {
+    if (!s || !origins || !directions || !ids || !t) return fail(RT_ERR_INVALID, "NULL argument");
+    if (!n) return RT_OK;
+    int rc;
+    if ((rc = upload_scene(s))) return rc;
+    if ((rc = s->w_rays.ensure((size_t)n * 8))) return rc;
+    float* d_o = s->w_rays.p; float* d_d = d_o + 3 * (size_t)n; float* d_t = d_d + 3 * (size_t)n; uint32_t* d_i = (uint32_t*)(d_t + n);
+    HIP_TRY(hipMemcpy(d_o, origins, (size_t)n * 12, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_d, directions, (size_t)n * 12, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_rays_closest, dim3(grid_for(s, n)), dim3(RT_BLOCK), 0, nullptr, s->dev, d_o, d_d, n, d_i, d_t);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(ids, d_i, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(t, d_t, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_occluded_rays(rt_scene* s, const float* origins, const float* directions, const float* max_dist, uint32_t n, uint8_t* out) {
+    if (!s || !origins || !directions || !max_dist || !out) return fail(RT_ERR_INVALID, "NULL argument");
+    if (!n) return RT_OK;
+    int rc;
+    if ((rc = upload_scene(s))) return rc;
+    if ((rc = s->w_rays.ensure((size_t)n * 8))) return rc;
+    float* d_o = s->w_rays.p; float* d_d = d_o + 3 * (size_t)n; float* d_m = d_d + 3 * (size_t)n; uint8_t* d_r = (uint8_t*)(d_m + n);
+    HIP_TRY(hipMemcpy(d_o, origins, (size_t)n * 12, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_d, directions, (size_t)n * 12, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_m, max_dist, (size_t)n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_rays_occluded, dim3(grid_for(s, n)), dim3(RT_BLOCK), 0, nullptr, s->dev, d_o, d_d, d_m, n, d_r);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, d_r, n, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_get_counters(const rt_scene* cs, rt_counters* out) {
+    if (!cs || !out) return fail(RT_ERR_INVALID, "NULL argument");
+    rt_scene* s = const_cast<rt_scene*>(cs);
+    memset(out, 0, sizeof *out);
+    if (!s->uploaded) return RT_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long st[ST_COUNT];
+    HIP_TRY(hipMemcpy(st, s->w_stats.p, sizeof st, hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof *out);
+    out->rays_closest = st[ST_RAYS_CLOSEST];
+    out->rays_shadow = st[ST_RAYS_SHADOW];
+    out->samples = s->samples;
+    if (out->rays_closest == 0 && s->launches[0] && s->samples) out->rays_closest = s->samples;   // primary cast: one ray per owned pixel
+    out->inner_nodes = st[ST_INNER]; out->tris_tested = st[ST_TRIS]; out->sphs_tested = st[ST_SPHS];
+    out->closest_hits_tri = st[ST_HITS_TRI]; out->closest_hits_sph = st[ST_HITS_SPH];
+    double ms[3] = {0, 0, 0};
+    for (size_t i = 0; i < s->events_used; ++i) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, s->events[i].a, s->events[i].b) == hipSuccess) ms[s->events[i].cls] += t;
+    }
+    out->kernel_ms_closest = ms[0]; out->kernel_ms_shadow = ms[1]; out->kernel_ms_shade = ms[2];
+    out->launches_closest = s->launches[0]; out->launches_shadow = s->launches[1];
+    return RT_OK;
+}
+
+int rt_set_option(rt_scene* s, const char* name, uint64_t value) {
+    if (!s || !name) return fail(RT_ERR_INVALID, "NULL argument");
+    const std::string n(name);
+    if (n == "stats") s->opt_stats = value != 0;
+    else if (n == "timing") s->opt_timing = value != 0;
+    else if (n == "max_paths") s->opt_max_paths = value ? value : (1ull << 22);
+    else return fail(RT_ERR_INVALID, "unknown option '" + n + "'");
+    return RT_OK;
+}
+
+uint32_t rt_tiles_per_shard(const rt_render_params* P) {
+    if (!P || !P->tile_w || !P->tile_h || !P->shard_count) return 0;
+    const uint32_t tiles = ((P->width + P->tile_w - 1) / P->tile_w) * ((P->height + P->tile_h - 1) / P->tile_h);
+    return (tiles + P->shard_count - 1) / P->shard_count;
+}
+
+int rt_tiles_pack(const rt_render_params* P, const void* frame_dev, void* compact_dev, uint32_t bytes_per_pixel, void* stream) {
+    int rc;
+    if ((rc = validate_params(P))) return rc;
+    if (!frame_dev || !compact_dev || bytes_per_pixel == 0 || bytes_per_pixel % 4) return fail(RT_ERR_INVALID, "bad tile copy arguments");
+    const uint32_t slots = rt_tiles_per_shard(P);
+    const uint32_t tiles_x = (P->width + P->tile_w - 1) / P->tile_w;
+    const uint64_t total = (uint64_t)slots * P->tile_w * P->tile_h;
+    uint64_t g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_tiles_copy, dim3((uint32_t)g), dim3(256), 0, (hipStream_t)stream, *P, tiles_x, P->shard_index, slots,
+                       (const uint32_t*)frame_dev, (uint32_t*)compact_dev, bytes_per_pixel / 4, 0);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_tiles_unpack(const rt_render_params* P, uint32_t shard_index, const void* compact_dev, void* frame_dev, uint32_t bytes_per_pixel,
+                    void* stream) {
+    int rc;
+    if ((rc = validate_params(P))) return rc;
+    if (!frame_dev || !compact_dev || bytes_per_pixel == 0 || bytes_per_pixel % 4 || shard_index >= P->shard_count)
+        return fail(RT_ERR_INVALID, "bad tile copy arguments");
+    const uint32_t slots = rt_tiles_per_shard(P);
+    const uint32_t tiles_x = (P->width + P->tile_w - 1) / P->tile_w;
+    const uint64_t total = (uint64_t)slots * P->tile_w * P->tile_h;
+    uint64_t g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_tiles_copy, dim3((uint32_t)g), dim3(256), 0, (hipStream_t)stream, *P, tiles_x, shard_index, slots,
+                       (const uint32_t*)compact_dev, (uint32_t*)frame_dev, bytes_per_pixel / 4, 1);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+// ---- host-side helpers ----
+void rt_screen_params(uint32_t width, uint32_t height, float fov, rt_render_params* p) {
+    const float w = (float)width, h = (float)height;
+    const float half_fov = fov * 0.5f;
+    const float start = sin_f(-half_fov);
+    p->width = width; p->height = height;
+    p->inv_w = 1.0f / w; p->inv_h = 1.0f / h;
+    p->start = start;
+    p->total = -2.0f * start;
+    p->aspect_ratio = w / h;
+    p->z = 1.7f;
+}
+
+int rt_scene_new_named(const char* name, const char* obj_path, rt_scene** out) {
+    if (!out || !name) return fail(RT_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    rt_scene* s = new rt_scene();
+    std::string err;
+    if (!make_named_scene(name, obj_path, nullptr, nullptr, 0, nullptr, 0, &s->host, &err)) { delete s; return fail(RT_ERR_INVALID, err); }
+    prepare_host(s);
+    *out = s;
+    return RT_OK;
+}
+
+int rt_scene_new_dragon_mesh(const float* vpos, const float* vnrm, uint32_t n_vert, const uint32_t* faces, uint32_t n_face, rt_scene** out) {
+    if (!out || !vpos || !faces) return fail(RT_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    for (size_t i = 0; i < 3 * (size_t)n_face; ++i)
+        if (faces[i] >= n_vert) return fail(RT_ERR_INVALID, "face index out of range");
+    rt_scene* s = new rt_scene();
+    std::string err;
+    if (!make_named_scene("dragon", nullptr, vpos, vnrm, n_vert, faces, n_face, &s->host, &err)) { delete s; return fail(RT_ERR_INVALID, err); }
+    prepare_host(s);
+    *out = s;
+    return RT_OK;
+}
+
+int rt_scene_export(const rt_scene* s, float* tri_pos, float* tri_nrm, uint32_t* tri_mat, float* sph, uint32_t* sph_mat, rt_material* mats) {
+    if (!s) return fail(RT_ERR_INVALID, "NULL scene");
+    const HostScene& h = s->host;
+    if (tri_pos && !h.tri_pos.empty()) memcpy(tri_pos, h.tri_pos.data(), h.tri_pos.size() * 4);
+    if (tri_nrm && !h.tri_nrm.empty()) memcpy(tri_nrm, h.tri_nrm.data(), h.tri_nrm.size() * 4);
+    if (tri_mat && !h.tri_mat.empty()) memcpy(tri_mat, h.tri_mat.data(), h.tri_mat.size() * 4);
+    if (sph && !h.sph.empty()) memcpy(sph, h.sph.data(), h.sph.size() * 4);
+    if (sph_mat && !h.sph_mat.empty()) memcpy(sph_mat, h.sph_mat.data(), h.sph_mat.size() * 4);
+    if (mats && !h.mats.empty()) memcpy(mats, h.mats.data(), h.mats.size() * sizeof(rt_material));
+    return RT_OK;
+}
+
+int rt_make_dragon_standin(uint32_t nu, uint32_t nv, float* vpos, float* vnrm, uint32_t* faces) {
+    if (nu < 3 || nv < 3 || !vpos || !vnrm || !faces) return fail(RT_ERR_INVALID, "bad stand-in mesh arguments");
+    make_dragon_standin(nu, nv, vpos, vnrm, faces);
+    return RT_OK;
+}
+
+// ---- debug probes ----
+int rt_debug_math(uint32_t op, const float* x, const float* y, uint32_t n, float* out) {
+    if (!x || !out || (op == 3 && !y)) return fail(RT_ERR_INVALID, "NULL argument");
+    if (!n) return RT_OK;
+    float *dx = nullptr, *dy = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc((void**)&dx, (size_t)n * 4));
+    HIP_TRY(hipMalloc((void**)&dy, (size_t)n * 4));
+    HIP_TRY(hipMalloc((void**)&dout, (size_t)n * 4));
+    HIP_TRY(hipMemcpy(dx, x, (size_t)n * 4, hipMemcpyHostToDevice));
+    if (y) HIP_TRY(hipMemcpy(dy, y, (size_t)n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_debug_math, dim3((n + 255) / 256), dim3(256), 0, nullptr, op, dx, dy, n, dout);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dout);
+    return RT_OK;
+}
+
+int rt_debug_rng(uint64_t seed, uint32_t pixel_index, uint32_t sample, uint32_t n, float* out) {
+    if (!out) return fail(RT_ERR_INVALID, "NULL argument");
+    if (!n) return RT_OK;
+    float* dout = nullptr;
+    HIP_TRY(hipMalloc((void**)&dout, (size_t)n * 4));
+    hipLaunchKernelGGL(k_debug_rng, dim3(1), dim3(64), 0, nullptr, mix64(seed), pixel_index, sample, n, dout);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(dout);
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,722 @@
+// rt_kernels.h — gfx950 kernels of the wavefront path tracer (device side of the hot path).
+//
+// One pass renders `npaths` camera samples in lock step.  Per bounce level k (bounces_left =
+// bounces - k, src/raytracer.rs:330-350) the host enqueues
+//   k_extend   closest-hit BVH traversal over the live ray queue      (Scene::intersect, mod.rs:406-447)
+//   k_shade_a  hit point + shading normal, terminates misses / depth 0 (mod.rs:58-67, raytracer.rs:339)
+//   k_shadow   one thread per (vertex, light, light sample): sample_l + any-hit traversal
+//                                                                      (objects.rs:96-118, mod.rs:452-491)
+//   k_shade_b  ordered sum of the light samples, emission, Russian roulette, BSDF sample, and
+//              wave64 ballot compaction of the surviving paths into the next ray queue
+//                                                                      (raytracer.rs:251-326)
+// and finally k_resolve adds the finished samples to their pixels in sample order
+// (raytracer.rs:236-239) and tone-maps (common.rs:46-58, raytracer.rs:43-51).
+//
+// The integrator is evaluated in exactly the association order of the reference's recursion: each
+// path keeps, per level, the direct term and the (reflected, cos, pdf) factors in HBM and folds
+// them from the last vertex back to the camera when it terminates (fold_path).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rt_math.h"
+#include "host_scene.h"
+
+namespace rt {
+
+#define RT_BLOCK 256
+#define RT_STACK_LDS 32          // traversal stack entries per lane staged in LDS (32 KiB per workgroup)
+#define RT_MISS 0xFFFFFFFFu
+#define RT_EPS 0.0000001f        // src/common.rs:6
+#define RT_PI 3.14159265358979323846f
+#define RT_ROULETTE 0.7f         // src/raytracer.rs:11
+#define RT_INFO_BLOCKER 0x80000000u
+
+struct DevScene {
+    const float4* nodes;     // 4 x float4 per inner node (64 B)
+    const float4* tris;      // 3 x float4 per triangle (48 B): (p1, rank) (e1, info) (e2, 0)
+    const float4* tri_nrm;   // 3 x float4 per triangle (48 B): vn1, vn2, vn3
+    const float4* sph;       // (center, radius)
+    const uint2* sph_aux;    // (rank, info)
+    const float4* mats;      // 2 x float4 per material: (bsdf bits, reflectance) (emittance, 0)
+    const uint32_t* lights;  // object indices
+    uint32_t n_tri, n_sph, n_lights, root;
+    uint32_t* ovf;           // traversal-stack overflow rows beyond RT_STACK_LDS: [row][global thread]
+    uint32_t ovf_stride;
+};
+
+struct TravStats {
+    uint32_t inner, tris, sphs;
+};
+
+struct PassCtx {
+    rt_render_params P;
+    uint64_t seed_mixed;
+    uint32_t tiles_x, n_tiles;
+    uint32_t pix0, npix, s0, spc;    // this pass: owned-pixel range [pix0, pix0+npix), samples [s0, s0+spc)
+    uint32_t npaths;                 // npix * spc
+    uint32_t n_groups, nlL;          // light-sample groups (lights, or 1 for the hemisphere estimator) and groups * light_samples
+    uint32_t* counts;                // live rays per level, [bounces + 2]
+    float4* ray_o[2];                // (origin, slot bits)   ping-pong by level parity
+    float4* ray_d[2];                // (direction, 0)
+    uint32_t* hit_id;
+    float* hit_t;
+    float4* vP;                      // (hit point, material index bits)
+    float4* vN;                      // (shading normal, alive flag)
+    uint64_t* rng;                   // per path slot
+    float4* contrib;                 // per (vertex, light sample): (rgb, visible)
+    float4* stackA;                  // [level][slot] (direct rgb, cos)
+    float4* stackB;                  // [level][slot] (reflected rgb, pdf)
+    float4* radiance;                // per path slot: finished sample
+    float4* accum;                   // per owned pixel, across sample chunks
+    const ulonglong2* jump;          // LCG jump-ahead (mul, add) by 2*j draws, j in [0, nlL]
+    unsigned long long* stats;       // device counters, see ST_*
+    uint8_t* rgba;                   // full frame
+};
+
+enum { ST_RAYS_CLOSEST = 0, ST_RAYS_SHADOW, ST_INNER, ST_TRIS, ST_SPHS, ST_HITS_TRI, ST_HITS_SPH, ST_COUNT };
+
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ vec3 xyz(float4 v) { return mk(v.x, v.y, v.z); }
+
+// Owned pixel `op` (tile-major, row-major inside the tile) -> image coordinates.
+__device__ __forceinline__ bool own_pixel_xy(const rt_render_params& P, uint32_t tiles_x, uint32_t op, uint32_t* x, uint32_t* y) {
+    const uint32_t tp = P.tile_w * P.tile_h;
+    const uint32_t k = op / tp, within = op - k * tp;
+    const uint32_t t = P.shard_index + k * P.shard_count;
+    const uint32_t ty = within / P.tile_w, tx = within - ty * P.tile_w;
+    *x = (t % tiles_x) * P.tile_w + tx;
+    *y = (t / tiles_x) * P.tile_h + ty;
+    return *x < P.width && *y < P.height;
+}
+
+// ScreenParams::screen_to_world, src/raytracer.rs:127-133
+__device__ __forceinline__ vec3 screen_to_world(const rt_render_params& P, uint32_t i, uint32_t j) {
+    const float iw = ((float)i + 0.5f) * P.inv_w;
+    const float jh = ((float)j + 0.5f) * P.inv_h;
+    const float xi = (P.start + iw * P.total) * P.aspect_ratio;
+    const float yi = -P.start - jh * P.total;
+    return unit3(mk(xi, yi, -P.z));
+}
+
+// bvh::ray::Ray::new as called from ray_to_bvh_ray (src/scene/mod.rs:506-512): the direction is
+// normalised again and the box tests use 1/d of that.
+struct BoxRay {
+    float ox, oy, oz, ix, iy, iz;
+    bool sx, sy, sz;
+};
+__device__ __forceinline__ BoxRay make_box_ray(vec3 o, vec3 d) {
+    const vec3 n = unit3(d);
+    BoxRay r;
+    r.ox = o.x; r.oy = o.y; r.oz = o.z;
+    r.ix = 1.0f / n.x; r.iy = 1.0f / n.y; r.iz = 1.0f / n.z;
+    r.sx = n.x < 0.0f; r.sy = n.y < 0.0f; r.sz = n.z < 0.0f;
+    return r;
+}
+// bvh 0.3.2 Ray::intersects_aabb (Williams slab test, no far bound; result = ray_max > 0) with the
+// comparisons in the crate's exact form so that NaN falls the same way.  *tnear (entry distance,
+// with the z slab folded in) is extra: it only orders and prunes, it never decides a hit.
+__device__ __forceinline__ bool slab(const BoxRay& r, float mnx, float mny, float mnz, float mxx, float mxy, float mxz, float* tnear) {
+    float ray_min = ((r.sx ? mxx : mnx) - r.ox) * r.ix;
+    float ray_max = ((r.sx ? mnx : mxx) - r.ox) * r.ix;
+    const float y_min = ((r.sy ? mxy : mny) - r.oy) * r.iy;
+    const float y_max = ((r.sy ? mny : mxy) - r.oy) * r.iy;
+    bool miss = (ray_min > y_max) || (y_min > ray_max);
+    if (y_min > ray_min) ray_min = y_min;
+    if (y_max < ray_max) ray_max = y_max;
+    const float z_min = ((r.sz ? mxz : mnz) - r.oz) * r.iz;
+    const float z_max = ((r.sz ? mnz : mxz) - r.oz) * r.iz;
+    miss = miss || (ray_min > z_max) || (z_min > ray_max);
+    *tnear = z_min > ray_min ? z_min : ray_min;
+    if (z_max < ray_max) ray_max = z_max;
+    return !miss && (ray_max > 0.0f);
+}
+
+// Object::intersect, triangle arm (src/scene/objects.rs:38-57); e1 = p2-p1 and e2 = p3-p1 are stored.
+__device__ __forceinline__ bool hit_triangle(vec3 p1, vec3 e1, vec3 e2, vec3 o, vec3 d, float* t_out) {
+    const vec3 s = sub(o, p1);
+    const vec3 s1 = cross3(d, e2);
+    const vec3 s2 = cross3(s, e1);
+    const float scalar = 1.0f / dot3(s1, e1);
+    const float t = dot3(s2, e2) * scalar;
+    const float b1 = dot3(s1, s) * scalar;
+    const float b2 = dot3(s2, d) * scalar;
+    if (b1 < 0.0f || b2 < 0.0f || b1 > 1.0f || b2 > 1.0f || b1 + b2 > 1.0f + RT_EPS || t < RT_EPS) return false;
+    *t_out = t;
+    return true;
+}
+// Object::intersect, sphere arm (src/scene/objects.rs:58-76): the nearer root, negative included.
+__device__ __forceinline__ bool hit_sphere(float4 cr, vec3 o, vec3 d, float* t_out) {
+    const vec3 l = sub(xyz(cr), o);
+    const float adj = dot3(l, d);
+    const float d2 = dot3(l, l) - (adj * adj);
+    const float radius2 = cr.w * cr.w;
+    if (d2 > radius2) return false;
+    const float thc = sqrtf(radius2 - d2);
+    const float t0 = adj - thc;
+    const float t1 = adj + thc;
+    if (t0 < 0.0f && t1 < 0.0f) return false;
+    *t_out = t0 < t1 ? t0 : t1;
+    return true;
+}
+
+// Per-lane traversal stack: RT_STACK_LDS entries in LDS ([entry][lane], conflict-free), deeper
+// entries in a global overflow row.
+struct Stack {
+    uint32_t* lds;      // &s_stack[threadIdx.x]
+    uint32_t* ovf;      // &sc.ovf[global thread]
+    uint32_t ovf_stride;
+    int sp;
+    __device__ __forceinline__ void push(uint32_t v) {
+        if (sp < RT_STACK_LDS) lds[sp * RT_BLOCK] = v;
+        else ovf[(size_t)(sp - RT_STACK_LDS) * ovf_stride] = v;
+        ++sp;
+    }
+    __device__ __forceinline__ uint32_t pop() {
+        --sp;
+        return sp < RT_STACK_LDS ? lds[sp * RT_BLOCK] : ovf[(size_t)(sp - RT_STACK_LDS) * ovf_stride];
+    }
+};
+
+// Pruning slack: a subtree is skipped only when its entry distance exceeds the current limit by
+// more than 2^-10 relative (absolute below 1).  The primitive's own t and the box entry are
+// rounded differently; the slack keeps the winner identical to the reference's unpruned search.
+__device__ __forceinline__ float prune_limit(float t) { return t + fmaxf(fabsf(t), 1.0f) * (1.0f / 1024.0f); }
+
+// Scene::intersect (src/scene/mod.rs:406-447).  The reference visits every leaf whose ancestors'
+// boxes the ray passes, in DFS order with the right child first, and keeps the first strictly
+// smallest distance.  Here: near child first, far child pushed, subtrees beyond the best distance
+// skipped, and equal distances resolved by the leaf's rank in the reference's visiting order —
+// the same (object, distance).
+template <bool STATS>
+__device__ __forceinline__ void closest_hit(const DevScene& sc, vec3 o, vec3 d, Stack& st, uint32_t* out_id, float* out_t, TravStats* ts) {
+    const BoxRay br = make_box_ray(o, d);
+    float best = __builtin_inff();
+    uint32_t best_id = RT_MISS, best_rank = 0xFFFFFFFFu;
+    st.sp = 0;
+    uint32_t cur = sc.root;
+    if (sc.n_tri + sc.n_sph == 0) { *out_id = RT_MISS; *out_t = best; return; }
+    for (;;) {
+        if (!(cur & LEAF_BIT)) {
+            const float4* n = sc.nodes + 4 * (size_t)cur;
+            const float4 a = n[0], b = n[1], c = n[2], k = n[3];
+            if (STATS) ts->inner++;
+            float tl, tr;
+            bool hl = slab(br, a.x, a.y, a.z, a.w, b.x, b.y, &tl);
+            bool hr = slab(br, b.z, b.w, c.x, c.y, c.z, c.w, &tr);
+            const float lim = prune_limit(best);
+            hl = hl && !(tl > lim);
+            hr = hr && !(tr > lim);
+            const uint32_t left = __float_as_uint(k.x), right = __float_as_uint(k.y);
+            if (hl && hr) {
+                const bool left_first = !(tr < tl);
+                st.push(left_first ? right : left);
+                cur = left_first ? left : right;
+                continue;
+            }
+            if (hl) { cur = left; continue; }
+            if (hr) { cur = right; continue; }
+        } else {
+            const uint32_t obj = cur & ~LEAF_BIT;
+            float t;
+            bool ok;
+            uint32_t rank;
+            if (obj < sc.n_tri) {
+                const float4* tp = sc.tris + 3 * (size_t)obj;
+                const float4 A = tp[0], B = tp[1], C = tp[2];
+                if (STATS) ts->tris++;
+                ok = hit_triangle(xyz(A), xyz(B), xyz(C), o, d, &t);
+                rank = __float_as_uint(A.w);
+            } else {
+                if (STATS) ts->sphs++;
+                ok = hit_sphere(sc.sph[obj - sc.n_tri], o, d, &t);
+                rank = sc.sph_aux[obj - sc.n_tri].x;
+            }
+            if (ok && (t < best || (t == best && best_id != RT_MISS && rank < best_rank))) {
+                best = t; best_id = obj; best_rank = rank;
+            }
+        }
+        if (st.sp == 0) break;
+        cur = st.pop();
+    }
+    *out_id = best_id;
+    *out_t = best;
+}
+
+// Scene::is_occluded (src/scene/mod.rs:452-491): true iff some visited leaf reports 0 < d < max_dist
+// on a non-emissive object.  Order-independent, so subtrees entered beyond max_dist are skipped.
+template <bool STATS>
+__device__ __forceinline__ bool any_hit(const DevScene& sc, vec3 o, vec3 d, float max_dist, Stack& st, TravStats* ts) {
+    const BoxRay br = make_box_ray(o, d);
+    const float lim = prune_limit(max_dist);
+    st.sp = 0;
+    uint32_t cur = sc.root;
+    if (sc.n_tri + sc.n_sph == 0) return false;
+    for (;;) {
+        if (!(cur & LEAF_BIT)) {
+            const float4* n = sc.nodes + 4 * (size_t)cur;
+            const float4 a = n[0], b = n[1], c = n[2], k = n[3];
+            if (STATS) ts->inner++;
+            float tl, tr;
+            bool hl = slab(br, a.x, a.y, a.z, a.w, b.x, b.y, &tl);
+            bool hr = slab(br, b.z, b.w, c.x, c.y, c.z, c.w, &tr);
+            hl = hl && !(tl > lim);
+            hr = hr && !(tr > lim);
+            const uint32_t left = __float_as_uint(k.x), right = __float_as_uint(k.y);
+            if (hl && hr) {
+                const bool left_first = !(tr < tl);
+                st.push(left_first ? right : left);
+                cur = left_first ? left : right;
+                continue;
+            }
+            if (hl) { cur = left; continue; }
+            if (hr) { cur = right; continue; }
+        } else {
+            const uint32_t obj = cur & ~LEAF_BIT;
+            float t;
+            bool ok;
+            uint32_t info;
+            if (obj < sc.n_tri) {
+                const float4* tp = sc.tris + 3 * (size_t)obj;
+                const float4 A = tp[0], B = tp[1], C = tp[2];
+                if (STATS) ts->tris++;
+                ok = hit_triangle(xyz(A), xyz(B), xyz(C), o, d, &t);
+                info = __float_as_uint(B.w);
+            } else {
+                if (STATS) ts->sphs++;
+                ok = hit_sphere(sc.sph[obj - sc.n_tri], o, d, &t);
+                info = sc.sph_aux[obj - sc.n_tri].y;
+            }
+            if (ok && t > 0.0f && t < max_dist && (info & RT_INFO_BLOCKER)) return true;
+        }
+        if (st.sp == 0) break;
+        cur = st.pop();
+    }
+    return false;
+}
+
+__device__ __forceinline__ uint32_t object_info(const DevScene& sc, uint32_t obj) {
+    return obj < sc.n_tri ? __float_as_uint(sc.tris[3 * (size_t)obj + 1].w) : sc.sph_aux[obj - sc.n_tri].y;
+}
+
+// Object::surface_normal (src/scene/objects.rs:228-230, 270-290): sphere (p-c)/|p-c|; triangle =
+// barycentric blend of the stored vertex normals, not re-normalised.
+__device__ __forceinline__ vec3 surface_normal(const DevScene& sc, uint32_t obj, vec3 point) {
+    if (obj >= sc.n_tri) return unit3(sub(point, xyz(sc.sph[obj - sc.n_tri])));
+    const float4* tp = sc.tris + 3 * (size_t)obj;
+    const vec3 p1 = xyz(tp[0]), v0 = xyz(tp[1]), v1 = xyz(tp[2]);
+    const vec3 v2 = sub(point, p1);
+    const float d00 = dot3(v0, v0), d01 = dot3(v0, v1), d11 = dot3(v1, v1), d20 = dot3(v2, v0), d21 = dot3(v2, v1);
+    const float denom = d00 * d11 - d01 * d01;
+    const float v = (d11 * d20 - d01 * d21) / denom;
+    const float w = (d00 * d21 - d01 * d20) / denom;
+    const float u = 1.0f - v - w;
+    const float4* np = sc.tri_nrm + 3 * (size_t)obj;
+    return add(add(scale(xyz(np[0]), u), scale(xyz(np[1]), v)), scale(xyz(np[2]), w));
+}
+
+// Vector::random_hemisphere / to_coord_space / random_sphere (src/scene/geo.rs:101-145)
+__device__ __forceinline__ vec3 random_hemisphere(uint64_t* rng) {
+    const float xi1 = next_f32(rng);
+    const float xi2 = next_f32(rng);
+    const float cos_theta = xi1;
+    const float sin_theta = sqrtf(1.0f - xi1 * xi1);
+    const float phi = 2.0f * RT_PI * xi2;
+    float sin_phi, cos_phi;
+    sincos_f(phi, &sin_phi, &cos_phi);
+    return mk(sin_theta * cos_phi, sin_theta * sin_phi, cos_theta);
+}
+__device__ __forceinline__ vec3 to_coord_space(vec3 v, vec3 n) {
+    vec3 t, b;
+    if (n.z < -0.9999999f) {
+        t = mk(0.0f, -1.0f, 0.0f);
+        b = mk(-1.0f, 0.0f, 0.0f);
+    } else {
+        const float a = 1.0f / (1.0f + n.z);
+        const float b_val = -n.x * n.y * a;
+        t = mk(1.0f - n.x * n.x * a, b_val, -n.x);
+        b = mk(b_val, 1.0f - n.y * n.y * a, -n.y);
+    }
+    return add(add(scale(t, v.x), scale(b, v.y)), scale(n, v.z));
+}
+__device__ __forceinline__ vec3 random_sphere(uint64_t* rng) {
+    const float xi1 = next_f32(rng);
+    const float xi2 = next_f32(rng);
+    const float theta = 2.0f * RT_PI * xi1;
+    const float phi = acos_f(1.0f - 2.0f * xi2);
+    float sp, cp, st, ct;
+    sincos_f(phi, &sp, &cp);
+    sincos_f(theta, &st, &ct);
+    return mk(sp * ct, sp * st, cp);
+}
+
+__device__ __forceinline__ bool spectrum_is_black(vec3 c) { return (c.x + c.y) + c.z <= RT_EPS; }   // src/common.rs:40-43
+__device__ __forceinline__ vec3 mul3(vec3 a, vec3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+
+// A path that ends at level k with radiance `color` unwinds the reference's recursion
+// (global_illumination, src/raytracer.rs:318-325): for each earlier level, scale the sub-path
+// radiance by reflected * cos * pdf unless it is black, then add that level's direct term.
+__device__ __forceinline__ void fold_path(const PassCtx& pc, uint32_t slot, uint32_t k, vec3 color) {
+    for (uint32_t j = k; j-- > 0;) {
+        const float4 A = pc.stackA[(size_t)j * pc.npaths + slot];
+        const float4 B = pc.stackB[(size_t)j * pc.npaths + slot];
+        if (!spectrum_is_black(color)) color = scale(scale(mul3(color, xyz(B)), A.w), B.w);
+        color = add(xyz(A), color);
+    }
+    pc.radiance[slot] = make_float4(color.x, color.y, color.z, 0.0f);
+}
+
+// wave64 ballot + prefix compaction: one atomic per wave reserves a run in the queue.
+__device__ __forceinline__ uint32_t wave_append(bool keep, uint32_t* counter) {
+    const unsigned long long active = __ballot(1);
+    const unsigned long long mask = __ballot(keep);
+    const uint32_t lane = __lane_id();
+    const int leader = __ffsll((long long)active) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader && mask) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+template <bool STATS>
+__device__ __forceinline__ void flush_stats(unsigned long long* stats, const TravStats& ts) {
+    if (!STATS) return;
+    uint32_t a = ts.inner, b = ts.tris, c = ts.sphs;
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_xor(a, off);
+        b += __shfl_xor(b, off);
+        c += __shfl_xor(c, off);
+    }
+    const unsigned long long active = __ballot(1);
+    if ((int)__lane_id() == __ffsll((long long)active) - 1) {
+        atomicAdd(&stats[ST_INNER], (unsigned long long)a);
+        atomicAdd(&stats[ST_TRIS], (unsigned long long)b);
+        atomicAdd(&stats[ST_SPHS], (unsigned long long)c);
+    }
+}
+
+#define RT_STACK_DECL                                                   \
+    __shared__ uint32_t s_stack[RT_STACK_LDS * RT_BLOCK];               \
+    Stack st;                                                           \
+    st.lds = &s_stack[threadIdx.x];                                     \
+    st.ovf = sc.ovf + (size_t)blockIdx.x * RT_BLOCK + threadIdx.x;      \
+    st.ovf_stride = sc.ovf_stride;                                      \
+    st.sp = 0
+
+// ---------------------------------------------------------------------------------------------
+// Primary-ray cast (debug_render_helper, src/raytracer.rs:394-416; BASELINE config 3).
+// ids/ts (optional) receive the winning object and distance; rgba (optional) the grey level.
+template <bool STATS>
+__global__ void __launch_bounds__(RT_BLOCK) k_primary(DevScene sc, rt_render_params P, uint32_t tiles_x, uint32_t n_own_pixels,
+                                                     uint32_t* ids, float* ts_out, uint8_t* rgba, unsigned long long* stats) {
+    RT_STACK_DECL;
+    TravStats tst = {0, 0, 0};
+    const vec3 cam = mk(P.cam[0], P.cam[1], P.cam[2]);
+    for (uint32_t op = blockIdx.x * RT_BLOCK + threadIdx.x; op < n_own_pixels; op += gridDim.x * RT_BLOCK) {
+        uint32_t x, y;
+        if (!own_pixel_xy(P, tiles_x, op, &x, &y)) continue;
+        const vec3 d = screen_to_world(P, x, y);
+        uint32_t id;
+        float t;
+        closest_hit<STATS>(sc, cam, d, st, &id, &t, &tst);
+        const size_t pi = (size_t)y * P.width + x;
+        if (ids) ids[pi] = id;
+        if (ts_out) ts_out[pi] = t;
+        if (rgba) {
+            float g = 0.0f;
+            if (id != RT_MISS) {
+                const float max_distance = 100.0f;
+                const float dm = (t != t) ? max_distance : (t < max_distance ? t : max_distance);
+                g = 0.7f * (1.0f - (dm / max_distance));
+            }
+            const uint32_t c = to_color(g);
+            reinterpret_cast<uint32_t*>(rgba)[pi] = c | (c << 8) | (c << 16) | 0xFF000000u;
+        }
+    }
+    flush_stats<STATS>(stats, tst);
+}
+
+// Camera rays for one pass (render_helper, src/raytracer.rs:224-241): every sample of a pixel
+// starts with the same primary ray and its own RNG stream.
+__global__ void __launch_bounds__(RT_BLOCK) k_generate(PassCtx pc) {
+    const rt_render_params& P = pc.P;
+    const vec3 cam = mk(P.cam[0], P.cam[1], P.cam[2]);
+    for (uint32_t q = blockIdx.x * RT_BLOCK + threadIdx.x; q < pc.npaths; q += gridDim.x * RT_BLOCK) {
+        const uint32_t pl = q / pc.spc, s = pc.s0 + (q - pl * pc.spc);
+        uint32_t x, y;
+        const bool valid = own_pixel_xy(P, pc.tiles_x, pc.pix0 + pl, &x, &y);
+        const uint32_t e = wave_append(valid, &pc.counts[0]);
+        if (!valid) continue;
+        pc.rng[q] = stream_seed(pc.seed_mixed, y * P.width + x, s);
+        const vec3 d = screen_to_world(P, x, y);
+        pc.ray_o[0][e] = make_float4(cam.x, cam.y, cam.z, __uint_as_float(q));
+        pc.ray_d[0][e] = make_float4(d.x, d.y, d.z, 0.0f);
+    }
+}
+
+template <bool STATS>
+__global__ void __launch_bounds__(RT_BLOCK) k_extend(DevScene sc, PassCtx pc, uint32_t level) {
+    RT_STACK_DECL;
+    TravStats tst = {0, 0, 0};
+    const uint32_t n = pc.counts[level];
+    const float4* ro = pc.ray_o[level & 1];
+    const float4* rd = pc.ray_d[level & 1];
+    for (uint32_t e = blockIdx.x * RT_BLOCK + threadIdx.x; e < n; e += gridDim.x * RT_BLOCK) {
+        uint32_t id;
+        float t;
+        closest_hit<STATS>(sc, xyz(ro[e]), xyz(rd[e]), st, &id, &t, &tst);
+        pc.hit_id[e] = id;
+        pc.hit_t[e] = t;
+    }
+    flush_stats<STATS>(pc.stats, tst);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&pc.stats[ST_RAYS_CLOSEST], (unsigned long long)n);
+}
+
+// cast_ray dispatch (src/raytracer.rs:337-349) up to the point where light sampling starts.
+__global__ void __launch_bounds__(RT_BLOCK) k_shade_a(DevScene sc, PassCtx pc, uint32_t level) {
+    const uint32_t n = pc.counts[level];
+    const uint32_t bounces_left = pc.P.bounces - level;
+    const float4* ro = pc.ray_o[level & 1];
+    const float4* rd = pc.ray_d[level & 1];
+    for (uint32_t e = blockIdx.x * RT_BLOCK + threadIdx.x; e < n; e += gridDim.x * RT_BLOCK) {
+        const float4 o4 = ro[e];
+        const uint32_t slot = __float_as_uint(o4.w);
+        const uint32_t id = pc.hit_id[e];
+        bool alive = false;
+        if (id == RT_MISS) {
+            fold_path(pc, slot, level, mk(0.0f, 0.0f, 0.0f));                      // raytracer.rs:348
+        } else {
+            const uint32_t mat = object_info(sc, id) & ~RT_INFO_BLOCKER;
+            if (bounces_left == 0) {
+                fold_path(pc, slot, level, xyz(sc.mats[2 * mat + 1]));             // zero_bounce_radiance, raytracer.rs:245-247
+            } else {
+                const vec3 o = xyz(o4), d = xyz(rd[e]);
+                const float min_dist = pc.hit_t[e] - RT_EPS;                       // RayIntersection::point, mod.rs:58-62
+                const vec3 p = add(o, scale(d, min_dist));
+                const vec3 nrm = surface_normal(sc, id, p);
+                pc.vP[e] = make_float4(p.x, p.y, p.z, __uint_as_float(mat));
+                pc.vN[e] = make_float4(nrm.x, nrm.y, nrm.z, 1.0f);
+                alive = true;
+            }
+        }
+        if (!alive) pc.vN[e] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const unsigned long long m = __ballot(alive);
+        const unsigned long long m_tri = __ballot(alive && id < sc.n_tri);
+        const unsigned long long active = __ballot(1);
+        if ((int)__lane_id() == __ffsll((long long)active) - 1 && m) {
+            const unsigned long long rays = (unsigned long long)__popcll(m) * pc.nlL;
+            atomicAdd(&pc.stats[pc.P.direct_estimator == RT_DIRECT_HEMISPHERE ? ST_RAYS_CLOSEST : ST_RAYS_SHADOW], rays);
+            atomicAdd(&pc.stats[ST_HITS_TRI], (unsigned long long)__popcll(m_tri));
+            atomicAdd(&pc.stats[ST_HITS_SPH], (unsigned long long)__popcll(m & ~m_tri));
+        }
+    }
+}
+
+// One thread per (vertex, light, light sample) of one_bounce_radiance_importance
+// (src/raytracer.rs:266-281): Object::sample_l (objects.rs:101-116) + the shadow ray.
+// HEMI = the hemisphere direct-lighting estimator (not in the reference source).
+template <bool STATS, bool HEMI>
+__global__ void __launch_bounds__(RT_BLOCK) k_shadow(DevScene sc, PassCtx pc, uint32_t level) {
+    RT_STACK_DECL;
+    TravStats tst = {0, 0, 0};
+    const uint32_t n = pc.counts[level] * pc.nlL;
+    const float4* ro = pc.ray_o[level & 1];
+    const uint32_t L = pc.P.light_samples;
+    for (uint32_t r = blockIdx.x * RT_BLOCK + threadIdx.x; r < n; r += gridDim.x * RT_BLOCK) {
+        const uint32_t e = r / pc.nlL, j = r - e * pc.nlL;
+        const float4 N4 = pc.vN[e];
+        if (N4.w == 0.0f) continue;
+        const float4 P4 = pc.vP[e];
+        const uint32_t slot = __float_as_uint(ro[e].w);
+        const ulonglong2 jm = pc.jump[j];
+        uint64_t rng = jm.x * pc.rng[slot] + jm.y;
+        const vec3 p = xyz(P4), nrm = xyz(N4);
+        const float4 m0 = sc.mats[2 * __float_as_uint(P4.w)];
+        // Object::bsdf, objects.rs:121-127
+        const vec3 reflected = __float_as_uint(m0.x) == RT_BSDF_DIFFUSE ? scale(mk(m0.y, m0.z, m0.w), 1.0f / RT_PI) : mk(0.0f, 0.0f, 0.0f);
+        float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (!HEMI) {
+            const uint32_t light = sc.lights[j / L];
+            const float4 cr = sc.sph[light - sc.n_tri];
+            const vec3 le = xyz(sc.mats[2 * (sc.sph_aux[light - sc.n_tri].y & ~RT_INFO_BLOCKER) + 1]);
+            const vec3 s = add(xyz(cr), scale(random_sphere(&rng), cr.w));          // Sphere::random_point, objects.rs:223-226
+            const vec3 ps = sub(s, p);
+            const float d_s = length3(ps);
+            const vec3 wi = scale(ps, 1.0f / d_s);
+            const float d_c = length3(sub(xyz(cr), p));
+            const float cos_a = (d_c * d_c + cr.w * cr.w - d_s * d_s) / (2.0f * d_c * cr.w);
+            const float pdf = 2.0f * RT_PI * (1.0f - cos_a);
+            if (!any_hit<STATS>(sc, p, wi, d_s, st, &tst)) {
+                const float cos_theta = fabsf(dot3(wi, nrm));
+                const vec3 c = scale(scale(mul3(le, reflected), cos_theta), pdf);   // raytracer.rs:279
+                out = make_float4(c.x, c.y, c.z, 1.0f);
+            }
+        } else {
+            const vec3 wi = to_coord_space(random_hemisphere(&rng), nrm);
+            uint32_t id;
+            float t;
+            closest_hit<STATS>(sc, p, unit3(wi), st, &id, &t, &tst);
+            if (id != RT_MISS) {
+                const vec3 le = xyz(sc.mats[2 * (object_info(sc, id) & ~RT_INFO_BLOCKER) + 1]);
+                const float cos_theta = fabsf(dot3(wi, nrm));
+                const vec3 c = scale(scale(mul3(le, reflected), cos_theta), 2.0f * RT_PI);
+                out = make_float4(c.x, c.y, c.z, 1.0f);
+            }
+        }
+        pc.contrib[r] = out;
+    }
+    flush_stats<STATS>(pc.stats, tst);
+}
+
+// The rest of one_bounce_radiance_importance and global_illumination (src/raytracer.rs:282-326).
+__global__ void __launch_bounds__(RT_BLOCK) k_shade_b(DevScene sc, PassCtx pc, uint32_t level) {
+    const uint32_t n = pc.counts[level];
+    const uint32_t bounces_left = pc.P.bounces - level;
+    const float4* ro = pc.ray_o[level & 1];
+    const float4* rd = pc.ray_d[level & 1];
+    float4* no = pc.ray_o[(level + 1) & 1];
+    float4* nd = pc.ray_d[(level + 1) & 1];
+    const uint32_t L = pc.P.light_samples;
+    const float inv_light_samples = 1.0f / (float)L;
+    // every lane of a wave runs the same number of iterations so that wave_append sees whole waves
+    const uint32_t n_round = (n + 63u) & ~63u;
+    for (uint32_t e = blockIdx.x * RT_BLOCK + threadIdx.x; e < n_round; e += gridDim.x * RT_BLOCK) {
+        bool cont = false;
+        float4 o_next = make_float4(0, 0, 0, 0), d_next = make_float4(0, 0, 0, 0);
+        if (e < n) {
+            const float4 N4 = pc.vN[e];
+            if (N4.w != 0.0f) {
+                const float4 P4 = pc.vP[e];
+                const uint32_t slot = __float_as_uint(ro[e].w);
+                const uint32_t mat = __float_as_uint(P4.w);
+                const float4 m0 = sc.mats[2 * mat], m1 = sc.mats[2 * mat + 1];
+                const vec3 p = xyz(P4), nrm = xyz(N4);
+                vec3 l = mk(0.0f, 0.0f, 0.0f);
+                const float4* cp = pc.contrib + (size_t)e * pc.nlL;
+                for (uint32_t g = 0; g < pc.n_groups; ++g) {
+                    vec3 color = mk(0.0f, 0.0f, 0.0f);
+                    for (uint32_t s = 0; s < L; ++s) {
+                        const float4 c = cp[g * L + s];
+                        if (c.w != 0.0f) color = add(color, xyz(c));
+                    }
+                    l = add(l, scale(color, inv_light_samples));                    // raytracer.rs:282
+                }
+                l = add(l, xyz(m1));                                                // raytracer.rs:284
+                if (bounces_left == 1) {
+                    fold_path(pc, slot, level, l);                                  // raytracer.rs:340-344
+                } else {
+                    const ulonglong2 jm = pc.jump[pc.nlL];
+                    uint64_t rng = jm.x * pc.rng[slot] + jm.y;
+                    if (!(next_f32(&rng) <= RT_ROULETTE)) {                         // weighted_coin_flip, common.rs:136-138
+                        fold_path(pc, slot, level, l);
+                    } else {
+                        const vec3 wo = xyz(rd[e]);
+                        vec3 wi, reflected;
+                        float pdf;
+                        const vec3 refl = mk(m0.y, m0.z, m0.w);
+                        if (__float_as_uint(m0.x) == RT_BSDF_DIFFUSE) {             // Object::sample_bsdf, objects.rs:130-148
+                            wi = to_coord_space(random_hemisphere(&rng), nrm);
+                            pdf = 2.0f * RT_PI;
+                            reflected = scale(refl, 1.0f / RT_PI);
+                        } else {
+                            wi = sub(wo, scale(scale(nrm, 2.0f), dot3(wo, nrm)));
+                            pdf = 1.0f;
+                            reflected = scale(refl, 1.0f / fabsf(dot3(wi, nrm)));
+                        }
+                        const float cos_theta = fabsf(dot3(wi, nrm));               // raytracer.rs:321
+                        pc.stackA[(size_t)level * pc.npaths + slot] = make_float4(l.x, l.y, l.z, cos_theta);
+                        pc.stackB[(size_t)level * pc.npaths + slot] = make_float4(reflected.x, reflected.y, reflected.z, pdf);
+                        pc.rng[slot] = rng;
+                        const vec3 dn = unit3(wi);                                  // Ray::new, geo.rs:19-24
+                        o_next = make_float4(p.x, p.y, p.z, __uint_as_float(slot));
+                        d_next = make_float4(dn.x, dn.y, dn.z, 0.0f);
+                        cont = true;
+                    }
+                }
+            }
+        }
+        const uint32_t q = wave_append(cont, &pc.counts[level + 1]);
+        if (cont) { no[q] = o_next; nd[q] = d_next; }
+    }
+}
+
+// render_helper's sample loop and set_pixel (src/raytracer.rs:235-240, 43-51).
+__global__ void __launch_bounds__(RT_BLOCK) k_resolve(PassCtx pc) {
+    const rt_render_params& P = pc.P;
+    for (uint32_t pl = blockIdx.x * RT_BLOCK + threadIdx.x; pl < pc.npix; pl += gridDim.x * RT_BLOCK) {
+        uint32_t x, y;
+        if (!own_pixel_xy(P, pc.tiles_x, pc.pix0 + pl, &x, &y)) continue;
+        float4 a = pc.s0 == 0 ? make_float4(0, 0, 0, 0) : pc.accum[pc.pix0 + pl];
+        for (uint32_t s = 0; s < pc.spc; ++s) {
+            const float4 r = pc.radiance[(size_t)pl * pc.spc + s];
+            a.x += r.x; a.y += r.y; a.z += r.z;
+        }
+        if (pc.s0 + pc.spc >= P.spp) {
+            const float inv = 1.0f / (float)P.spp;
+            const uint32_t r8 = to_color(a.x * inv), g8 = to_color(a.y * inv), b8 = to_color(a.z * inv);
+            reinterpret_cast<uint32_t*>(pc.rgba)[(size_t)y * P.width + x] = r8 | (g8 << 8) | (b8 << 16) | 0xFF000000u;
+        } else {
+            pc.accum[pc.pix0 + pl] = a;
+        }
+    }
+}
+
+// Arbitrary rays (rt_intersect_rays / rt_occluded_rays).
+__global__ void __launch_bounds__(RT_BLOCK) k_rays_closest(DevScene sc, const float* org, const float* dir, uint32_t n, uint32_t* ids, float* ts_out) {
+    RT_STACK_DECL;
+    TravStats tst = {0, 0, 0};
+    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
+        uint32_t id;
+        float t;
+        closest_hit<false>(sc, mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]), mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), st, &id, &t, &tst);
+        ids[i] = id;
+        ts_out[i] = t;
+    }
+}
+__global__ void __launch_bounds__(RT_BLOCK) k_rays_occluded(DevScene sc, const float* org, const float* dir, const float* maxd, uint32_t n, uint8_t* out) {
+    RT_STACK_DECL;
+    TravStats tst = {0, 0, 0};
+    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK)
+        out[i] = any_hit<false>(sc, mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]), mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), maxd[i], st, &tst) ? 1 : 0;
+}
+
+// Screen-tile pack / unpack for the multi-GPU gather.  words = bytes_per_pixel / 4.
+__global__ void k_tiles_copy(rt_render_params P, uint32_t tiles_x, uint32_t shard, uint32_t n_slots, const uint32_t* src, uint32_t* dst,
+                             uint32_t words, int unpack) {
+    const uint32_t tp = P.tile_w * P.tile_h;
+    const size_t total = (size_t)n_slots * tp;
+    rt_render_params Q = P;
+    Q.shard_index = shard;
+    for (size_t op = (size_t)blockIdx.x * blockDim.x + threadIdx.x; op < total; op += (size_t)gridDim.x * blockDim.x) {
+        uint32_t x, y;
+        const uint32_t tiles_total = tiles_x * ((P.height + P.tile_h - 1) / P.tile_h);
+        const uint32_t t = shard + (uint32_t)(op / tp) * P.shard_count;
+        if (t >= tiles_total) continue;
+        if (!own_pixel_xy(Q, tiles_x, (uint32_t)op, &x, &y)) continue;
+        const size_t pi = (size_t)y * P.width + x;
+        for (uint32_t w = 0; w < words; ++w) {
+            if (unpack) dst[pi * words + w] = src[op * words + w];
+            else dst[op * words + w] = src[pi * words + w];
+        }
+    }
+}
+
+__global__ void k_debug_math(uint32_t op, const float* x, const float* y, uint32_t n, float* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r;
+    switch (op) {
+        case 0: r = sin_f(x[i]); break;
+        case 1: r = cos_f(x[i]); break;
+        case 2: r = acos_f(x[i]); break;
+        case 3: r = pow_f(x[i], y[i]); break;
+        default: r = (float)to_color(x[i]); break;
+    }
+    out[i] = r;
+}
+__global__ void k_debug_rng(uint64_t seed_mixed, uint32_t pixel_index, uint32_t sample, uint32_t n, float* out) {
+    if (blockIdx.x || threadIdx.x) return;
+    uint64_t s = stream_seed(seed_mixed, pixel_index, sample);
+    for (uint32_t i = 0; i < n; ++i) out[i] = next_f32(&s);
+}
+
+}  // namespace rt

@@ -1,0 +1,173 @@
+// rt_math.h — arithmetic shared by the host scene code and the gfx950 kernels.
+//
+// Everything here is built from single IEEE-754 operations (no contraction: the library is
+// compiled with -ffp-contract=off; HIP's f32 divide and sqrt are the correctly rounded forms),
+// so a value computed on the host and on the device is the same bit pattern.
+//
+// Vector operations follow nalgebra 0.23.2 as wrapped by the reference's Point/Vector
+// (src/scene/geo.rs:33-235): dot = (x*x' + y*y') + z*z', normalize = v / norm (three divides).
+// sin/cos/acos/pow stand in for the libm calls behind f32::sin, f32::cos, f32::acos, f32::powf
+// (src/scene/geo.rs:106-143, src/common.rs:57): fixed double-precision evaluations rounded once
+// to f32 (correctly rounded on all sampled inputs; tests/test_oracle_math.py).
+#pragma once
+#include <stdint.h>
+#include <string.h>
+#include <math.h>
+
+#if defined(__HIP__)
+#define RT_HD __host__ __device__ inline __attribute__((always_inline))
+#else
+#define RT_HD inline
+#endif
+
+namespace rt {
+
+struct vec3 {
+    float x, y, z;
+};
+RT_HD vec3 mk(float x, float y, float z) { vec3 v; v.x = x; v.y = y; v.z = z; return v; }
+RT_HD vec3 add(vec3 a, vec3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_HD vec3 sub(vec3 a, vec3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_HD vec3 scale(vec3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+RT_HD float dot3(vec3 a, vec3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+RT_HD vec3 cross3(vec3 a, vec3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+RT_HD float length3(vec3 a) { return sqrtf(dot3(a, a)); }
+RT_HD vec3 unit3(vec3 a) { float n = length3(a); return mk(a.x / n, a.y / n, a.z / n); }
+
+RT_HD float bits_to_float(uint32_t b) { float f; memcpy(&f, &b, 4); return f; }
+RT_HD uint32_t float_to_bits(float f) { uint32_t b; memcpy(&b, &f, 4); return b; }
+RT_HD double bits_to_double(uint64_t b) { double d; memcpy(&d, &b, 8); return d; }
+RT_HD uint64_t double_to_bits(double d) { uint64_t b; memcpy(&b, &d, 8); return b; }
+
+// ---- sin / cos: Cody-Waite reduction by pi/2 (33-bit head), Taylor kernels on |r| <= pi/4 ----
+RT_HD void sincos_f(float xf, float* s_out, float* c_out) {
+    const double x = (double)xf;
+    const double kd = floor(x * 0.63661977236758134308 + 0.5);
+    const int k = (int)kd;
+    const double r = (x - kd * 1.57079632673412561417e+00) - kd * 6.07710050650619224932e-11;
+    const double z = r * r;
+    double ps = 1.0 / 6227020800.0;
+    ps = -1.0 / 39916800.0 + z * ps;
+    ps = 1.0 / 362880.0 + z * ps;
+    ps = -1.0 / 5040.0 + z * ps;
+    ps = 1.0 / 120.0 + z * ps;
+    ps = -1.0 / 6.0 + z * ps;
+    const double s = r + r * (z * ps);
+    double pc = 1.0 / 87178291200.0;
+    pc = -1.0 / 479001600.0 + z * pc;
+    pc = 1.0 / 3628800.0 + z * pc;
+    pc = -1.0 / 40320.0 + z * pc;
+    pc = 1.0 / 720.0 + z * pc;
+    pc = -1.0 / 24.0 + z * pc;
+    pc = 0.5 + z * pc;
+    const double c = 1.0 - z * pc;
+    const int q = k & 3;
+    const double so = q == 0 ? s : (q == 1 ? c : (q == 2 ? -s : -c));
+    const double co = q == 0 ? c : (q == 1 ? -s : (q == 2 ? -c : s));
+    *s_out = (float)so;
+    *c_out = (float)co;
+}
+RT_HD float sin_f(float x) { float s, c; sincos_f(x, &s, &c); return s; }
+RT_HD float cos_f(float x) { float s, c; sincos_f(x, &s, &c); return c; }
+
+// ---- acos: fdlibm rational asin(x) = x + x*R(x^2) on |x| <= 1/2, half-angle form above ----
+RT_HD double asin_ratio(double z) {
+    const double p = z * (1.66666666666666657415e-01 +
+                          z * (-3.25565818622400915405e-01 +
+                               z * (2.01212532134862925881e-01 +
+                                    z * (-4.00555345006794114027e-02 + z * (7.91534994289814532176e-04 + z * 3.47933107596021167570e-05)))));
+    const double q = 1.0 + z * (-2.40339491173441421878e+00 +
+                                z * (2.02094576023350569471e+00 + z * (-6.88283971605453293030e-01 + z * 7.70381505559019352791e-02)));
+    return p / q;
+}
+RT_HD float acos_f(float xf) {
+    const double x = (double)xf;
+    const double PI_D = 3.14159265358979311600e+00, PIO2_D = 1.57079632679489655800e+00;
+    if (x != x) return xf;
+    if (x >= 1.0) return x == 1.0 ? 0.0f : bits_to_float(0x7fc00000u);
+    if (x <= -1.0) return x == -1.0 ? (float)PI_D : bits_to_float(0x7fc00000u);
+    const double ax = x < 0.0 ? -x : x;
+    if (ax <= 0.5) return (float)(PIO2_D - (x + x * asin_ratio(x * x)));
+    const double z = (1.0 - ax) * 0.5;
+    const double s = sqrt(z);
+    const double w = s + s * asin_ratio(z);
+    if (x > 0.0) return (float)(2.0 * w);
+    return (float)(PI_D - 2.0 * w);
+}
+
+// ---- pow(x, y) = exp(y * log(x)) for x >= 0 (tone map base is clamped to [0,1]) ----
+RT_HD float pow_f(float xf, float yf) {
+    if (xf != xf) return xf;
+    if (xf == 0.0f) return 0.0f;
+    if (xf == 1.0f) return 1.0f;
+    const double x = (double)xf, y = (double)yf;
+    uint64_t bits = double_to_bits(x);
+    int e = (int)((bits >> 52) & 0x7ff) - 1023;
+    double m = bits_to_double((bits & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);
+    if (m > 1.41421356237309514547) { m *= 0.5; e += 1; }
+    const double s = (m - 1.0) / (m + 1.0);
+    const double z = s * s;
+    double p = 1.0 / 17.0;
+    p = 1.0 / 15.0 + z * p;
+    p = 1.0 / 13.0 + z * p;
+    p = 1.0 / 11.0 + z * p;
+    p = 1.0 / 9.0 + z * p;
+    p = 1.0 / 7.0 + z * p;
+    p = 1.0 / 5.0 + z * p;
+    p = 1.0 / 3.0 + z * p;
+    const double logm = 2.0 * (s + s * (z * p));
+    const double LN2 = 6.93147180559945286227e-01;
+    const double t = y * ((double)e * LN2 + logm);
+    const double kd = floor(t * 1.44269504088896338700e+00 + 0.5);
+    const double r = t - kd * LN2;
+    double q = 1.0 / 479001600.0;
+    q = 1.0 / 39916800.0 + r * q;
+    q = 1.0 / 3628800.0 + r * q;
+    q = 1.0 / 362880.0 + r * q;
+    q = 1.0 / 40320.0 + r * q;
+    q = 1.0 / 5040.0 + r * q;
+    q = 1.0 / 720.0 + r * q;
+    q = 1.0 / 120.0 + r * q;
+    q = 1.0 / 24.0 + r * q;
+    q = 1.0 / 6.0 + r * q;
+    q = 0.5 + r * q;
+    const double er = 1.0 + (r + (r * r) * q);
+    const int k = (int)kd;
+    if (k < -1000) return 0.0f;
+    return (float)(er * bits_to_double((uint64_t)(k + 1023) << 52));
+}
+
+// Spectrum::to_color (src/common.rs:46-58): clamp, gamma 1/2.2, *255, `as u8` (truncate, NaN -> 0).
+RT_HD uint32_t to_color(float intensity) {
+    float c = intensity;
+    if (c < 0.0f) c = 0.0f;
+    if (c > 1.0f) c = 1.0f;
+    const float v = pow_f(c, 1.0f / 2.2f) * 255.0f;
+    if (v > 255.0f) return 255u;
+    if (!(v == v)) return 0u;
+    if (v <= 0.0f) return 0u;
+    return (uint32_t)(int)v;
+}
+
+// ---- RNG: the fastrand 1.4.0 generator (PCG-XSH-RR 64/32) with one stream per (pixel, sample) ----
+RT_HD uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+#define RT_PCG_MUL 6364136223846793005ULL
+#define RT_PCG_INC 1442695040888963407ULL
+RT_HD uint64_t stream_seed(uint64_t seed_mixed, uint32_t pixel_index, uint32_t sample) {
+    return mix64(seed_mixed ^ (((uint64_t)pixel_index << 32) | (uint64_t)sample));   // seed_mixed = mix64(seed)
+}
+RT_HD float next_f32(uint64_t* state) {
+    const uint64_t s = *state;
+    *state = s * RT_PCG_MUL + RT_PCG_INC;
+    const uint32_t x = (uint32_t)((s ^ (s >> 18)) >> 27);
+    const uint32_t rot = (uint32_t)(s >> 59);
+    const uint32_t u = (x >> rot) | (x << ((32u - rot) & 31u));
+    return bits_to_float(0x3F800000u | (u >> 9)) - 1.0f;
+}
+
+}  // namespace rt

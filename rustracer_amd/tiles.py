@@ -1,0 +1,65 @@
+"""Screen-tile sharding across GPUs and the framebuffer gather.
+
+No reference counterpart: the reference parallelises over image columns on one host
+(src/raytracer.rs:197-216).  Here every rank renders the tiles t with t % world == rank into its own
+full-size frame, packs them into a compact buffer, and one all_gather (RCCL on GPUs, gloo in the CPU
+tests) moves every rank's tiles to all ranks, where they are scattered into the final frame
+(`Canvas` reads rank 0's).  The RNG streams are keyed by the global pixel index, so the image does
+not depend on the number of ranks.
+"""
+import numpy as np
+import torch
+
+
+def tiles_per_shard(width, height, tile_w, tile_h, world):
+    tiles = ((width + tile_w - 1) // tile_w) * ((height + tile_h - 1) // tile_h)
+    return (tiles + world - 1) // world
+
+
+def tile_index_map(width, height, tile_w, tile_h, shard, world):
+    """Pixel index (y*width + x) of every compact slot of `shard`, -1 where the slot is padding
+    (tile beyond the image or pixel beyond its edge).  Same enumeration as own_pixel_xy in the kernels."""
+    tiles_x = (width + tile_w - 1) // tile_w
+    tiles_y = (height + tile_h - 1) // tile_h
+    n_slots = tiles_per_shard(width, height, tile_w, tile_h, world)
+    k = np.arange(n_slots, dtype=np.int64)[:, None, None]
+    ty = np.arange(tile_h, dtype=np.int64)[None, :, None]
+    tx = np.arange(tile_w, dtype=np.int64)[None, None, :]
+    t = shard + k * world
+    x = (t % tiles_x) * tile_w + tx
+    y = (t // tiles_x) * tile_h + ty
+    valid = (t < tiles_x * tiles_y) & (x < width) & (y < height)
+    idx = np.where(valid, y * width + x, -1)
+    return idx.reshape(-1)
+
+
+def pack_tiles(frame, index_map):
+    """frame: [H*W, C] tensor -> compact [n_slots*tile_pixels, C] (padding slots zero)."""
+    idx = torch.as_tensor(index_map, device=frame.device)
+    out = frame[idx.clamp(min=0)]
+    out[idx < 0] = 0
+    return out
+
+
+def unpack_tiles(compact, index_map, frame):
+    idx = torch.as_tensor(index_map, device=frame.device)
+    valid = idx >= 0
+    frame[idx[valid]] = compact[valid]
+    return frame
+
+
+def gather_frame(frame, width, height, tile_w, tile_h, rank, world, group=None):
+    """frame: this rank's [H, W, C] tensor with its own tiles rendered.  Returns the complete frame
+    (on every rank; one all_gather of equal-sized compact buffers)."""
+    import torch.distributed as dist
+    if world == 1:
+        return frame
+    c = frame.shape[-1]
+    flat = frame.reshape(-1, c)
+    mine = pack_tiles(flat, tile_index_map(width, height, tile_w, tile_h, rank, world)).contiguous()
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    out = torch.zeros_like(flat)
+    for r in range(world):
+        unpack_tiles(parts[r], tile_index_map(width, height, tile_w, tile_h, r, world), out)
+    return out.reshape(frame.shape)
