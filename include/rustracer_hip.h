@@ -66,10 +66,10 @@ typedef struct rt_counters {
     uint64_t rays_closest;    /* intersect calls */
     uint64_t rays_shadow;     /* is_occluded calls */
     uint64_t samples;         /* camera samples = owned pixels * spp */
-    uint64_t inner_nodes;     /* inner nodes fetched           (filled only when stats are enabled) */
-    uint64_t tris_tested;     /* ray-triangle tests            (stats) */
-    uint64_t sphs_tested;     /* ray-sphere tests              (stats) */
-    uint64_t closest_hits_tri, closest_hits_sph; /* shaded vertices by primitive type (stats) */
+    /* traversal work per ray class, filled only when the "stats" option is on: */
+    uint64_t closest_inner, closest_tris, closest_sphs;   /* inner nodes fetched / triangles / spheres tested by intersect rays */
+    uint64_t shadow_inner, shadow_tris, shadow_sphs;      /* ... by is_occluded rays */
+    uint64_t closest_hits_tri, closest_hits_sph; /* shaded vertices by primitive type */
     double   kernel_ms_closest, kernel_ms_shadow, kernel_ms_shade;  /* HIP-event time per kernel class (timing enabled) */
     uint64_t launches_closest, launches_shadow;
 } rt_counters;

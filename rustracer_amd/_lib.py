@@ -50,7 +50,8 @@ class SceneInfo(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [("rays_closest", C.c_uint64), ("rays_shadow", C.c_uint64), ("samples", C.c_uint64),
-                ("inner_nodes", C.c_uint64), ("tris_tested", C.c_uint64), ("sphs_tested", C.c_uint64),
+                ("closest_inner", C.c_uint64), ("closest_tris", C.c_uint64), ("closest_sphs", C.c_uint64),
+                ("shadow_inner", C.c_uint64), ("shadow_tris", C.c_uint64), ("shadow_sphs", C.c_uint64),
                 ("closest_hits_tri", C.c_uint64), ("closest_hits_sph", C.c_uint64),
                 ("kernel_ms_closest", C.c_double), ("kernel_ms_shadow", C.c_double), ("kernel_ms_shade", C.c_double),
                 ("launches_closest", C.c_uint64), ("launches_shadow", C.c_uint64)]

@@ -604,7 +604,8 @@ int rt_get_counters(const rt_scene* cs, rt_counters* out) {
     out->rays_shadow = st[ST_RAYS_SHADOW];
     out->samples = s->samples;
     if (out->rays_closest == 0 && s->launches[0] && s->samples) out->rays_closest = s->samples;   // primary cast: one ray per owned pixel
-    out->inner_nodes = st[ST_INNER]; out->tris_tested = st[ST_TRIS]; out->sphs_tested = st[ST_SPHS];
+    out->closest_inner = st[ST_C_INNER]; out->closest_tris = st[ST_C_TRIS]; out->closest_sphs = st[ST_C_SPHS];
+    out->shadow_inner = st[ST_S_INNER]; out->shadow_tris = st[ST_S_TRIS]; out->shadow_sphs = st[ST_S_SPHS];
     out->closest_hits_tri = st[ST_HITS_TRI]; out->closest_hits_sph = st[ST_HITS_SPH];
     double ms[3] = {0, 0, 0};
     for (size_t i = 0; i < s->events_used; ++i) {

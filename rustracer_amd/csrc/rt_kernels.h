@@ -73,7 +73,8 @@ struct PassCtx {
     uint8_t* rgba;                   // full frame
 };
 
-enum { ST_RAYS_CLOSEST = 0, ST_RAYS_SHADOW, ST_INNER, ST_TRIS, ST_SPHS, ST_HITS_TRI, ST_HITS_SPH, ST_COUNT };
+// traversal work is counted per ray class: [ST_C_*] closest-hit rays, [ST_S_*] shadow (any-hit) rays
+enum { ST_RAYS_CLOSEST = 0, ST_RAYS_SHADOW, ST_C_INNER, ST_C_TRIS, ST_C_SPHS, ST_S_INNER, ST_S_TRIS, ST_S_SPHS, ST_HITS_TRI, ST_HITS_SPH, ST_COUNT };
 
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ vec3 xyz(float4 v) { return mk(v.x, v.y, v.z); }
@@ -378,7 +379,7 @@ __device__ __forceinline__ uint32_t wave_append(bool keep, uint32_t* counter) {
 }
 
 template <bool STATS>
-__device__ __forceinline__ void flush_stats(unsigned long long* stats, const TravStats& ts) {
+__device__ __forceinline__ void flush_stats(unsigned long long* stats, const TravStats& ts, int base) {
     if (!STATS) return;
     uint32_t a = ts.inner, b = ts.tris, c = ts.sphs;
     for (int off = 32; off > 0; off >>= 1) {
@@ -388,9 +389,9 @@ __device__ __forceinline__ void flush_stats(unsigned long long* stats, const Tra
     }
     const unsigned long long active = __ballot(1);
     if ((int)__lane_id() == __ffsll((long long)active) - 1) {
-        atomicAdd(&stats[ST_INNER], (unsigned long long)a);
-        atomicAdd(&stats[ST_TRIS], (unsigned long long)b);
-        atomicAdd(&stats[ST_SPHS], (unsigned long long)c);
+        atomicAdd(&stats[base], (unsigned long long)a);
+        atomicAdd(&stats[base + 1], (unsigned long long)b);
+        atomicAdd(&stats[base + 2], (unsigned long long)c);
     }
 }
 
@@ -432,7 +433,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_primary(DevScene sc, rt_render_par
             reinterpret_cast<uint32_t*>(rgba)[pi] = c | (c << 8) | (c << 16) | 0xFF000000u;
         }
     }
-    flush_stats<STATS>(stats, tst);
+    flush_stats<STATS>(stats, tst, ST_C_INNER);
 }
 
 // Camera rays for one pass (render_helper, src/raytracer.rs:224-241): every sample of a pixel
@@ -467,7 +468,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_extend(DevScene sc, PassCtx pc, ui
         pc.hit_id[e] = id;
         pc.hit_t[e] = t;
     }
-    flush_stats<STATS>(pc.stats, tst);
+    flush_stats<STATS>(pc.stats, tst, ST_C_INNER);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&pc.stats[ST_RAYS_CLOSEST], (unsigned long long)n);
 }
 
@@ -564,7 +565,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow(DevScene sc, PassCtx pc, ui
         }
         pc.contrib[r] = out;
     }
-    flush_stats<STATS>(pc.stats, tst);
+    flush_stats<STATS>(pc.stats, tst, HEMI ? ST_C_INNER : ST_S_INNER);
 }
 
 // The rest of one_bounce_radiance_importance and global_illumination (src/raytracer.rs:282-326).

@@ -1,0 +1,351 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same
+seeded inputs.  Bars: primary-hit IDs, distances, ray counts and RGBA8 images bit-exact
+(the north-star gate is IDs bit-exact and PSNR >= 40 dB; the shared arithmetic is built so that
+the stronger bar holds).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def psnr(a, b):
+    mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+    return float("inf") if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse)
+
+
+def oracle_params(**kw):
+    from oracle import binding as ob
+    return ob.make_params(**kw)
+
+
+def to_rt_params(op):
+    """oracle RenderParams -> rt_render_params (same byte layout)."""
+    from rustracer_amd._lib import RenderParams
+    p = RenderParams()
+    assert C.sizeof(p) == C.sizeof(op)
+    C.memmove(C.byref(p), C.byref(op), C.sizeof(p))
+    return p
+
+
+def gpu_render(scene, p):
+    from rustracer_amd._lib import check, lib, ptr
+    rgba = np.zeros((p.height, p.width, 4), np.uint8)
+    check(lib().rt_render(scene.handle, C.byref(p), ptr(rgba), None, None))
+    return rgba, scene.counters()
+
+
+def gpu_cast(scene, p):
+    from rustracer_amd._lib import check, lib, ptr
+    ids = np.full((p.height, p.width), 0xFFFFFFFF, np.uint32)
+    ts = np.full((p.height, p.width), np.inf, np.float32)
+    check(lib().rt_cast_primary(scene.handle, C.byref(p), ptr(ids), ptr(ts)))
+    return ids, ts
+
+
+@pytest.fixture(scope="module")
+def scenes(gpu, teapot_obj):
+    """(oracle scene, HIP scene) pairs built from the same constructors."""
+    from oracle import binding as ob
+    import rustracer_amd as ra
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            if name.startswith("dragon"):
+                nu, nv = (500, 100) if name == "dragon_small" else (120, 40)
+                vp, vn, f = ra.dragon_standin_mesh(nu, nv)
+                cache[name] = (ob.OracleScene.dragon_mesh(vp, vn, f), ra.Scene.from_dragon_mesh(vp, vn, f))
+            else:
+                cache[name] = (ob.OracleScene.named(name, teapot_obj), ra.Scene._named(name, teapot_obj))
+        return cache[name]
+    return get
+
+
+# ---------------------------------------------------------------------------------------------
+def test_device_math_bit_exact(gpu):
+    """sin/cos/acos/pow/to_color evaluated on the GPU == the oracle's, bit for bit."""
+    from oracle import binding as ob
+    from rustracer_amd._lib import check, lib, ptr
+    L = ob.lib()
+    rng = np.random.default_rng(1)
+    x = np.concatenate([np.linspace(-0.8, 6.3, 20001), rng.uniform(0, 6.2831855, 20000)]).astype(np.float32)
+    xa = np.concatenate([np.linspace(-1, 1, 20001), rng.uniform(-1, 1, 20000), [1.5, -1.5, np.nan]]).astype(np.float32)
+    xp = np.concatenate([np.linspace(0, 1, 20001), rng.uniform(0, 1, 20000), [0.0, 1.0, np.nan]]).astype(np.float32)
+    yp = np.full(xp.shape, np.float32(1.0) / np.float32(2.2), np.float32)
+    xc = np.concatenate([np.linspace(-0.5, 1.5, 20001), [np.nan, np.inf, -np.inf, 0.0, 1.0, 0.5]]).astype(np.float32)
+    for op, arr, y, f in ((0, x, None, L.orc_math_sin), (1, x, None, L.orc_math_cos), (2, xa, None, L.orc_math_acos)):
+        out = np.zeros_like(arr)
+        check(lib().rt_debug_math(op, ptr(arr), None, arr.shape[0], ptr(out)))
+        ref = np.array([f(C.c_float(float(v))) for v in arr], np.float32)
+        assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), "op %d differs" % op
+    out = np.zeros_like(xp)
+    check(lib().rt_debug_math(3, ptr(xp), ptr(yp), xp.shape[0], ptr(out)))
+    ref = np.array([L.orc_math_pow(C.c_float(float(v)), C.c_float(float(yp[0]))) for v in xp], np.float32)
+    assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+    out = np.zeros_like(xc)
+    check(lib().rt_debug_math(4, ptr(xc), None, xc.shape[0], ptr(out)))
+    ref = np.array([L.orc_to_color(C.c_float(float(v))) for v in xc], np.float32)
+    assert np.array_equal(out, ref)
+
+
+def test_device_rng_stream(gpu):
+    from oracle import binding as ob
+    from rustracer_amd._lib import check, lib, ptr
+    for seed, pix, s in ((0x5EED, 0, 0), (0x5EED, 123456, 7), (1, 2073599, 255), (2 ** 63 + 5, 4_000_000_000, 1023)):
+        got = np.zeros(64, np.float32)
+        ref = np.zeros(64, np.float32)
+        check(lib().rt_debug_rng(seed, pix, s, 64, ptr(got)))
+        ob.lib().orc_rng_stream(seed, pix, s, 64, ref.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(got, ref)
+        assert (got >= 0).all() and (got < 1).all()
+
+
+def test_known_rays(scenes):
+    """SURVEY.md §8c items 2-4 on the GPU: central-ray tie-break, negative sphere t, occlusion rules."""
+    osc, gsc = scenes("specular")
+    org = np.zeros((4, 3), np.float32)
+    d = np.array([[0, 0, -1], [0.3, 0.1, -1], [0, 1, 0], [0, 0, 1]], np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    gi, gt = gsc.intersect_rays(org, d)
+    oi, ot = osc.intersect_rays(org, d)
+    assert np.array_equal(gi, oi) and np.array_equal(gt.view(np.uint32), ot.view(np.uint32))
+    assert gt[0] == 68.0 and gi[0] in (4, 5)           # back wall, on the shared diagonal
+    assert gi[3] == 0xFFFFFFFF                           # through the open front
+    # origin inside the red sphere (object 12): the reference returns the negative root (objects.rs:70-75)
+    c = np.array([[20.0 / 3.0, -14.0, -48.0 - 20.0 / 3.0]], np.float32)
+    gi, gt = gsc.intersect_rays(c, np.array([[0, 0, -1]], np.float32))
+    oi, ot = osc.intersect_rays(c, np.array([[0, 0, -1]], np.float32))
+    assert gi[0] == oi[0] == 12 and gt[0] == ot[0] and gt[0] < 0
+    # occlusion: emissive sphere never blocks; walls do; max_dist respected
+    o = np.array([[0, 0, -40], [0, 0, -40], [0, 0, -40], [0, -19, -58]], np.float32)
+    dd = np.array([[0, 1, 0], [0, -1, 0], [0, -1, 0], [0, 1, 0]], np.float32)
+    md = np.array([100, 100, 10, 100], np.float32)
+    assert np.array_equal(gsc.occluded_rays(o, dd, md), osc.occluded_rays(o, dd, md))
+
+
+@pytest.mark.parametrize("name", ["specular", "diffuse", "teapot", "triangle", "sphere_on_plane", "dragon_tiny"])
+def test_random_rays_match_oracle(scenes, name):
+    """Scene::intersect / is_occluded on random rays from random origins: ids, t and occlusion bit-exact."""
+    osc, gsc = scenes(name)
+    rng = np.random.default_rng(7)
+    n = 20000
+    org = rng.uniform([-19, -19, -66], [19, 19, 0], (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    d[:50, 0] = 0.0                                     # zero components: inf / NaN paths of the slab test
+    d[50:100, 1] = 0.0
+    gi, gt = gsc.intersect_rays(org, d)
+    oi, ot = osc.intersect_rays(org, d)
+    assert np.array_equal(gi, oi)
+    assert np.array_equal(gt.view(np.uint32), ot.view(np.uint32))
+    md = rng.uniform(0.5, 60, n).astype(np.float32)
+    assert np.array_equal(gsc.occluded_rays(org, d, md), osc.occluded_rays(org, d, md))
+
+
+@pytest.mark.parametrize("name,w,h", [("specular", 600, 600), ("teapot", 512, 512), ("teapot", 333, 177), ("dragon_small", 480, 270),
+                                      ("triangle", 128, 128)])
+def test_primary_ids_bit_exact(scenes, name, w, h):
+    """BASELINE config 3 gate: 100 % of primary-hit object ids (and distances) identical."""
+    osc, gsc = scenes(name)
+    op = oracle_params(width=w, height=h)
+    oi, ot, _ = osc.cast_primary(op)
+    gi, gt = gpu_cast(gsc, to_rt_params(op))
+    assert np.array_equal(gi, oi), "%d pixels differ" % int((gi != oi).sum())
+    assert np.array_equal(gt.view(np.uint32), ot.view(np.uint32))
+    if name == "specular":                              # i == j looks along the back wall's shared diagonal (tie-break)
+        diag = gi[np.arange(200, 400), np.arange(200, 400)]
+        assert set(np.unique(diag)) <= {4, 5, 11, 12}
+
+
+def test_debug_render_matches_oracle(scenes):
+    osc, gsc = scenes("teapot")
+    op = oracle_params(width=200, height=150, mode=0)
+    ref = osc.render(op)["rgba"]
+    got, _ = gpu_render(gsc, to_rt_params(op))
+    assert np.array_equal(got, ref)
+
+
+CASES = [
+    # name, w, h, spp, L, bounces, estimator
+    ("teapot", 96, 96, 8, 4, 1, 0),              # config 2 shape: direct lighting, light importance sampling
+    ("teapot", 64, 64, 4, 4, 8, 0),              # GI, depth 8
+    ("specular", 96, 64, 8, 4, 8, 0),            # mirror sphere: specular branch, non-square aspect
+    ("diffuse", 64, 64, 4, 2, 50, 0),            # reference default depth 50
+    ("dragon_tiny", 64, 64, 4, 8, 8, 0),         # config 4 shape at toy size
+    ("specular_teapot", 64, 64, 4, 4, 8, 0),     # config 5 shape at toy size
+    ("sphere_on_plane", 64, 64, 16, 8, 1, 1),    # config 1: hemisphere estimator
+    ("teapot", 64, 64, 4, 4, 3, 1),              # hemisphere estimator inside GI
+    ("triangle", 64, 64, 4, 4, 4, 0),            # specular triangle with blended normals
+    ("teapot", 48, 48, 3, 5, 0, 0),              # bounces = 0: emission only
+]
+
+
+@pytest.mark.parametrize("name,w,h,spp,L,b,est", CASES)
+def test_render_matches_oracle(scenes, name, w, h, spp, L, b, est):
+    osc, gsc = scenes(name)
+    op = oracle_params(width=w, height=h, spp=spp, light_samples=L, bounces=b, direct_estimator=est, seed=0x5EED)
+    ref = osc.render(op)
+    got, cnt = gpu_render(gsc, to_rt_params(op))
+    assert cnt["rays_closest"] == ref["intersect_calls"]
+    assert cnt["rays_shadow"] == ref["occluded_calls"]
+    assert cnt["samples"] == w * h * spp
+    ndiff = int((got != ref["rgba"]).sum())
+    assert psnr(got, ref["rgba"]) >= 40.0                # north-star gate
+    assert ndiff == 0, "%d of %d bytes differ (PSNR %.1f dB)" % (ndiff, got.size, psnr(got, ref["rgba"]))
+
+
+def test_render_independent_of_pass_size_and_shards(scenes):
+    """Chunking samples/pixels into passes and splitting tiles over shards never changes a pixel."""
+    osc, gsc = scenes("teapot")
+    op = oracle_params(width=80, height=72, spp=6, light_samples=3, bounces=5)
+    ref = osc.render(op)["rgba"]
+    p = to_rt_params(op)
+    for max_paths in (1 << 22, 80 * 72 * 2, 1000, 64):
+        gsc.set_option("max_paths", max_paths)
+        got, _ = gpu_render(gsc, p)
+        assert np.array_equal(got, ref), "max_paths=%d" % max_paths
+    gsc.set_option("max_paths", 1 << 22)
+    from rustracer_amd._lib import check, lib, ptr
+    frame = np.zeros((72, 80, 4), np.uint8)
+    total_samples = 0
+    for shard in range(3):
+        q = p.copy()
+        q.tile_w, q.tile_h, q.shard_index, q.shard_count = 16, 8, shard, 3
+        check(lib().rt_render(gsc.handle, C.byref(q), ptr(frame), None, None))
+        total_samples += gsc.counters()["samples"]
+    assert np.array_equal(frame, ref)
+    assert total_samples == 80 * 72 * 6
+
+
+def test_stats_option_counts_and_same_image(scenes):
+    """The instrumented kernels (algorithmic-bytes counters) produce the same image and sane counts."""
+    osc, gsc = scenes("teapot")
+    op = oracle_params(width=64, height=64, spp=2, light_samples=2, bounces=2)
+    p = to_rt_params(op)
+    plain, c0 = gpu_render(gsc, p)
+    gsc.set_option("stats", 1)
+    inst, c1 = gpu_render(gsc, p)
+    gsc.set_option("stats", 0)
+    assert np.array_equal(plain, inst)
+    assert c1["rays_closest"] == c0["rays_closest"] and c1["rays_shadow"] == c0["rays_shadow"]
+    assert c1["closest_inner"] > c1["rays_closest"] and c1["closest_tris"] > 0 and c1["closest_sphs"] > 0
+    assert c1["shadow_inner"] > c1["rays_shadow"] and c1["shadow_tris"] > 0
+    assert c0["closest_inner"] == 0 and c0["shadow_inner"] == 0
+    assert c1["closest_hits_tri"] + c1["closest_hits_sph"] > 0
+    # closest-hit rays: ordered traversal with pruning never does more work than the reference's
+    # unpruned search (shadow rays exit early in either order, so only primary rays are compared)
+    gsc.set_option("stats", 1)
+    gi, _ = gpu_cast(gsc, p)
+    c2 = gsc.counters()
+    gsc.set_option("stats", 0)
+    oi, _, ocnt = osc.cast_primary(op)
+    assert np.array_equal(gi, oi)
+    assert c2["rays_closest"] == 64 * 64 == int(ocnt[0])
+    assert c2["closest_inner"] + c2["closest_tris"] + c2["closest_sphs"] <= int(ocnt[2])
+
+
+def test_golden_fixtures_on_gpu(gpu, teapot_obj):
+    """The committed golden vectors (made by tests/golden/make_golden.py from the oracle) on the HIP path."""
+    import json
+    import rustracer_amd as ra
+    from oracle import binding as ob
+    manifest = json.load(open(os.path.join(GOLDEN, "manifest.json")))
+    for case in manifest["cases"]:
+        data = np.load(os.path.join(GOLDEN, case["file"]))
+        if case["scene"] == "dragon_tiny":
+            vp, vn, f = ra.dragon_standin_mesh(120, 40)
+            sc = ra.Scene.from_dragon_mesh(vp, vn, f)
+        else:
+            sc = ra.Scene._named(case["scene"], teapot_obj)
+        op = ob.make_params(**case["params"])
+        p = to_rt_params(op)
+        if case["kind"] == "ids":
+            gi, gt = gpu_cast(sc, p)
+            assert np.array_equal(gi, data["ids"]) and np.array_equal(gt.view(np.uint32), data["t"].view(np.uint32)), case["file"]
+        else:
+            got, _ = gpu_render(sc, p)
+            assert np.array_equal(got, data["rgba"]), case["file"]
+        sc.close()
+
+
+def test_interrupt_and_progress(scenes):
+    """interrupt is polled between passes (raytracer.rs:184-204); progress reaches 100 (raytracer.rs:220)."""
+    from rustracer_amd._lib import RT_ERR_INTERRUPTED, lib, ptr
+    _, gsc = scenes("teapot")
+    p = to_rt_params(oracle_params(width=64, height=64, spp=4, light_samples=2, bounces=2))
+    rgba = np.zeros((64, 64, 4), np.uint8)
+    prog, intr = C.c_uint32(0), C.c_uint32(0)
+    assert lib().rt_render(gsc.handle, C.byref(p), ptr(rgba), C.byref(prog), C.byref(intr)) == 0
+    assert prog.value == 100
+    intr.value = 1
+    assert lib().rt_render(gsc.handle, C.byref(p), ptr(rgba), C.byref(prog), C.byref(intr)) == RT_ERR_INTERRUPTED
+
+
+def test_error_paths(gpu):
+    """The ABI returns codes where the reference panics (triangle lights: objects.rs:98-100)."""
+    import rustracer_amd as ra
+    from rustracer_amd._lib import RT_ERR_INVALID, RT_ERR_UNSUPPORTED, RtError, lib, ptr
+    tri = np.array([[-1, -1, -5, 1, -1, -5, 0, 1, -5]], np.float32)
+    nrm = np.array([[0, 0, 1] * 3], np.float32)
+    mats = np.zeros((1, 8), np.uint32)
+    mats[0, 4:7] = np.array([1, 1, 1], np.float32).view(np.uint32)        # emissive triangle
+    sc = ra.Scene.from_arrays(tri, nrm, [0], np.zeros((0, 4)), [], mats)
+    p = to_rt_params(oracle_params(width=16, height=16, spp=1, light_samples=1, bounces=1))
+    rgba = np.zeros((16, 16, 4), np.uint8)
+    assert lib().rt_render(sc.handle, C.byref(p), ptr(rgba), None, None) == RT_ERR_UNSUPPORTED
+    p.spp = 0
+    assert lib().rt_render(sc.handle, C.byref(p), ptr(rgba), None, None) == RT_ERR_INVALID
+    with pytest.raises(RtError):
+        ra.Scene.from_arrays(tri, nrm, [3], np.zeros((0, 4)), [], mats)    # material index out of range
+
+
+def test_tile_pack_unpack_kernels(gpu):
+    """rt_tiles_pack / rt_tiles_unpack (device) agree with the index-map version used for the gather."""
+    import torch
+    from rustracer_amd import tiles
+    from rustracer_amd._lib import check, lib
+    w, h, tw, th, world = 100, 70, 32, 16, 3
+    p = to_rt_params(oracle_params(width=w, height=h))
+    p.tile_w, p.tile_h, p.shard_count = tw, th, world
+    frame = torch.arange(w * h, dtype=torch.int32, device="cuda").reshape(h, w, 1).contiguous()
+    out = torch.zeros_like(frame)
+    for r in range(world):
+        p.shard_index = r
+        n = lib().rt_tiles_per_shard(C.byref(p)) * tw * th
+        compact = torch.zeros(n, dtype=torch.int32, device="cuda")
+        check(lib().rt_tiles_pack(C.byref(p), frame.data_ptr(), compact.data_ptr(), 4, None))
+        torch.cuda.synchronize()
+        ref = tiles.pack_tiles(frame.reshape(-1, 1), tiles.tile_index_map(w, h, tw, th, r, world)).reshape(-1)
+        assert torch.equal(compact, ref)
+        check(lib().rt_tiles_unpack(C.byref(p), r, compact.data_ptr(), out.data_ptr(), 4, None))
+    torch.cuda.synchronize()
+    assert torch.equal(out, frame)
+
+
+def test_python_api_mirror_renders(gpu, teapot_obj, tmp_path, monkeypatch):
+    """Scene/Raytracer/Canvas mirror: headless image mode writes ./dump/<secs>.png (canvas.rs:41-110)."""
+    import rustracer_amd as ra
+    monkeypatch.chdir(tmp_path)
+    cfg = ra.Config(screen_width=64, screen_height=48, samples_per_pixel=2, light_samples=2, bounces=3, image_mode=True)
+    rt = ra.Raytracer.new(cfg, ra.Scene.new_teapot(teapot_obj))
+    assert rt.inner.rendering_mode == ra.RenderingMode.Debug      # raytracer.rs:445
+    rt.start()
+    assert rt.inner.render_progress == 100 and not rt.inner.is_rendering
+    path = rt.inner.canvas.last_path
+    assert path and os.path.exists(path) and open(path, "rb").read(8) == b"\x89PNG\r\n\x1a\n"
+    buf = rt.inner.pixel_buffer.data.reshape(48, 64, 4)
+    assert (buf[:, :, 3] == 255).all() and buf[:, :, :3].max() > 0
+    rt.move_camera((0.0, 0.0, -1.0))
+    assert rt.inner.camera_position == [0.0, 0.0, -2.0]            # CAMERA_SPEED, raytracer.rs:18, 479
+    rt.toggle_rendering_mode()
+    assert rt.inner.rendering_mode == ra.RenderingMode.Debug
+    rt.render(True)
+    rt.reset_camera()
+    assert rt.inner.camera_position == [0.0, 0.0, 0.0]
