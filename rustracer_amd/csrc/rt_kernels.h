@@ -24,7 +24,7 @@
 namespace rt {
 
 #define RT_BLOCK 256
-#define RT_STACK_LDS 32          // traversal stack entries per lane staged in LDS (32 KiB per workgroup)
+#define RT_STACK_LDS 16          // traversal stack entries per lane staged in LDS (16 KiB per workgroup)
 #define RT_MISS 0xFFFFFFFFu
 #define RT_EPS 0.0000001f        // src/common.rs:6
 #define RT_PI 3.14159265358979323846f
@@ -455,7 +455,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_generate(PassCtx pc) {
 }
 
 template <bool STATS>
-__global__ void __launch_bounds__(RT_BLOCK) k_extend(DevScene sc, PassCtx pc, uint32_t level) {
+__global__ void __launch_bounds__(RT_BLOCK, 8) k_extend(DevScene sc, PassCtx pc, uint32_t level) {
     RT_STACK_DECL;
     TravStats tst = {0, 0, 0};
     const uint32_t n = pc.counts[level];
@@ -516,7 +516,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_a(DevScene sc, PassCtx pc, u
 // (src/raytracer.rs:266-281): Object::sample_l (objects.rs:101-116) + the shadow ray.
 // HEMI = the hemisphere direct-lighting estimator (not in the reference source).
 template <bool STATS, bool HEMI>
-__global__ void __launch_bounds__(RT_BLOCK) k_shadow(DevScene sc, PassCtx pc, uint32_t level) {
+__global__ void __launch_bounds__(RT_BLOCK, 8) k_shadow(DevScene sc, PassCtx pc, uint32_t level) {
     RT_STACK_DECL;
     TravStats tst = {0, 0, 0};
     const uint32_t n = pc.counts[level] * pc.nlL;

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Summarise a tools/profile.sh output directory (rocprofv3 CSVs) into one markdown file for profiles/.
+
+    python tools/summarize_prof.py gpurun_out/prof_<tag> profiles/<name>.md
+"""
+import csv
+import glob
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    m = re.search(r"rt::(k_[a-z_]+(?:<[^>]*>)?)", name)
+    return m.group(1) if m else None
+
+
+def main(src, dst):
+    out = ["# rocprofv3 summary: %s" % os.path.basename(src.rstrip("/")), ""]
+    for line in open(os.path.join(src, "trace.log")):
+        if line.startswith("{"):
+            out += ["bench line of the traced run:", "", "```", line.strip(), "```", ""]
+    stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+    if stats:
+        out += ["## `rocprofv3 --kernel-trace --stats` (kernel_stats.csv)", "", "| kernel | calls | total ms | avg ms | % | min ms | max ms |",
+                "|---|---|---|---|---|---|---|"]
+        for r in csv.DictReader(open(stats[0])):
+            out.append("| `%s` | %s | %.3f | %.4f | %s | %.4f | %.4f |" % (short(r["Name"]) or r["Name"][:60], r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                                                                       float(r["AverageNs"]) / 1e6, r["Percentage"], float(r["MinNs"]) / 1e6, float(r["MaxNs"]) / 1e6))
+        out.append("")
+    # PMC: sum each counter over the dispatches of each of our kernels
+    agg = defaultdict(lambda: defaultdict(float))
+    calls = defaultdict(lambda: defaultdict(int))
+    meta = {}
+    for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            if not k:
+                continue
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            calls[k][r["Counter_Name"]] += 1
+            meta[k] = (r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Scratch_Size"])
+    if agg:
+        out += ["## PMC counters (separate `--pmc` passes; sums over all dispatches of the kernel in the run)", ""]
+        counters = sorted({c for k in agg for c in agg[k]})
+        out += ["| kernel | VGPR | SGPR | LDS B | scratch | " + " | ".join(counters) + " |", "|---|---|---|---|---|" + "---|" * len(counters)]
+        for k in sorted(agg):
+            m = meta[k]
+            out.append("| `%s` | %s | %s | %s | %s | " % (k, m[0], m[2], m[3], m[4]) + " | ".join("%.4g" % agg[k].get(c, float("nan")) for c in counters) + " |")
+        out += ["", "## Derived (per kernel)", "",
+                "| kernel | dispatches | VALU lane utilisation = THREAD_CYCLES_VALU / (ACTIVE_INST_VALU*64)... see note | VALU busy = ACTIVE_INST_VALU*4 / WAVE_CYCLES... | L2 hit rate | FETCH GB (x2 corrected) | WRITE GB |",
+                "|---|---|---|---|---|---|---|"]
+        for k in sorted(agg):
+            a = agg[k]
+            lane = a.get("SQ_THREAD_CYCLES_VALU", 0) / max(a.get("SQ_ACTIVE_INST_VALU", 0) * 64.0, 1)
+            busy = a.get("SQ_ACTIVE_INST_VALU", 0) / max(a.get("SQ_WAVE_CYCLES", 0), 1)
+            hit = a.get("TCC_HIT_sum", 0) / max(a.get("TCC_HIT_sum", 0) + a.get("TCC_MISS_sum", 0), 1)
+            # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB; gfx950 FETCH_SIZE reads 1/2 of wide coalesced reads (MI355X_MICROARCH.md §HBM)
+            fetch = a.get("FETCH_SIZE", 0) * 1024 * 2 / 1e9
+            write = a.get("WRITE_SIZE", 0) * 1024 / 1e9
+            out.append("| `%s` | %d | %.3f | %.3f | %.4f | %.3f | %.3f |" % (k, calls[k].get("SQ_WAVES", 0), lane, busy, hit, fetch, write))
+        out += ["", "Notes: SQ_*_CYCLES counters are in quad-cycles (MI355X_MICROARCH.md); lane utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU) "
+                "is the mean fraction of the 64 lanes active per VALU instruction; 'VALU busy' = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES is the fraction of "
+                "wave-resident time spent issuing VALU work.", ""]
+    os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
+    open(dst, "w").write("\n".join(out) + "\n")
+    print("\n".join(out))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
