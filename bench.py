@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample (0 = skip)")
     ap.add_argument("--stats-spp", type=int, default=4, help="spp of the instrumented pass that measures bytes/ray (0 = skip)")
     ap.add_argument("--max-paths", type=int, default=0)
+    ap.add_argument("--opt", action="append", default=[], help="name=value passed to rt_set_option (tuning experiments)")
     return ap.parse_args()
 
 
@@ -84,6 +85,9 @@ def main():
     n_tri = scene.info.n_tri
     if a.max_paths:
         scene.set_option("max_paths", a.max_paths)
+    for kv in a.opt:
+        k, val = kv.split("=")
+        scene.set_option(k, int(val))
 
     cfg = Config(screen_width=a.width, screen_height=a.height, samples_per_pixel=a.spp, light_samples=a.light_samples,
                  bounces=a.bounces, seed=a.seed)
@@ -178,6 +182,8 @@ def main():
         "samples_per_s": round(samples * a.steps / elapsed, 1),
         "rays_per_step": int(rays_per_step), "rays_closest_per_step": int(rays_closest), "rays_shadow_per_step": int(rays_shadow),
         "rays_per_sample": round(rays_per_step / max(samples, 1), 2),
+        "kernel_ms_last_step": {"trace_shadow": round(cnt["kernel_ms_shadow"], 2), "trace_closest": round(cnt["kernel_ms_closest"], 2),
+                                "shade_generate_resolve": round(cnt["kernel_ms_shade"], 2)},
         "roofline": roofline, "cpu_baseline": cpu,
     }
     print(json.dumps(out), flush=True)

@@ -78,6 +78,13 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("%s is missing: build it with `make -C rustracer_amd/csrc` (or __graft_entry__.build()); "
                            "there is no CPU fallback" % LIB_PATH)
+    # PyTorch ships its own HIP runtime (torch/lib/libamdhip64.so).  One process must use one runtime:
+    # load torch's first so that this library binds to the same one and can share device memory,
+    # streams and RCCL communicators with torch tensors.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, u32, u64, f32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_float
     L.rt_last_error.restype = C.c_char_p

@@ -21,6 +21,8 @@ struct HostScene {
 };
 
 const uint32_t LEAF_BIT = 0x80000000u;
+const uint32_t NONBLOCK_BIT = 0x40000000u;   // device copy only: leaf of an emissive object (never blocks a shadow ray, mod.rs:481)
+const uint32_t OBJECT_MASK = 0x3FFFFFFFu;
 
 // Device BVH: inner nodes only, 16 words (64 B) each:
 //   {l_min xyz, l_max xyz, r_min xyz, r_max xyz, left, right, 0, 0}

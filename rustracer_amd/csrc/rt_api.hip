@@ -70,7 +70,7 @@ struct rt_scene {
     // workspace (grow-only; no allocation in steady state)
     DevBuf<uint32_t> w_counts, w_hit_id;
     DevBuf<float> w_hit_t;
-    DevBuf<float4> w_ray_o[2], w_ray_d[2], w_vP, w_vN, w_contrib, w_stackA, w_stackB, w_radiance, w_accum;
+    DevBuf<float4> w_ray_o[2], w_ray_d[2], w_vP, w_vN, w_contrib, w_direct, w_stackA, w_stackB, w_radiance, w_accum;
     DevBuf<uint64_t> w_rng;
     DevBuf<ulonglong2> w_jump;
     uint32_t jump_nlL = 0xFFFFFFFFu;
@@ -82,6 +82,7 @@ struct rt_scene {
 
     bool opt_stats = false, opt_timing = false;
     uint64_t opt_max_paths = 1ull << 22;
+    uint32_t opt_inner_min = 12;
     uint32_t grid_max = 2048;
 
     std::vector<EventPair> events;
@@ -167,7 +168,19 @@ int upload_scene(rt_scene* s) {
     if ((rc = s->d_mats.ensure(mats.size()))) return rc;
     if ((rc = s->d_lights.ensure(s->lights.size() ? s->lights.size() : 1))) return rc;
     if (ovf_rows && (rc = s->d_ovf.ensure((size_t)ovf_rows * s->grid_max * RT_BLOCK))) return rc;
-    if (n_inner) HIP_TRY(hipMemcpy(s->d_nodes.p, b.words.data(), n_inner * 64, hipMemcpyHostToDevice));
+    if (n_inner) {
+        // device copy of the nodes: leaves of emissive objects carry NONBLOCK_BIT
+        std::vector<uint32_t> words(b.words);
+        for (size_t i = 0; i < n_inner; ++i)
+            for (int c = 12; c <= 13; ++c) {
+                const uint32_t ref = words[16 * i + c];
+                if (!(ref & LEAF_BIT)) continue;
+                const uint32_t obj = ref & OBJECT_MASK;
+                const rt_material& m = obj < T ? h.mats[h.tri_mat[obj]] : h.mats[h.sph_mat[obj - T]];
+                if (!scene_is_black(m.emittance)) words[16 * i + c] = ref | NONBLOCK_BIT;
+            }
+        HIP_TRY(hipMemcpy(s->d_nodes.p, words.data(), n_inner * 64, hipMemcpyHostToDevice));
+    }
     if (T) {
         HIP_TRY(hipMemcpy(s->d_tris.p, tris.data(), tris.size() * sizeof(float4), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(s->d_tri_nrm.p, nrm.data(), nrm.size() * sizeof(float4), hipMemcpyHostToDevice));
@@ -181,7 +194,12 @@ int upload_scene(rt_scene* s) {
     d.nodes = s->d_nodes.p; d.tris = s->d_tris.p; d.tri_nrm = s->d_tri_nrm.p; d.sph = s->d_sph.p; d.sph_aux = s->d_sph_aux.p;
     d.mats = s->d_mats.p; d.lights = s->d_lights.p;
     d.n_tri = T; d.n_sph = S; d.n_lights = (uint32_t)s->lights.size(); d.root = b.root;
+    if ((b.root & LEAF_BIT) && T + S == 1) {
+        const rt_material& m = T ? h.mats[h.tri_mat[0]] : h.mats[h.sph_mat[0]];
+        if (!scene_is_black(m.emittance)) d.root |= NONBLOCK_BIT;
+    }
     d.ovf = s->d_ovf.p; d.ovf_stride = s->grid_max * RT_BLOCK;
+    d.inner_min = s->opt_inner_min;
     if ((rc = s->w_stats.ensure(ST_COUNT))) return rc;
     HIP_TRY(hipMemset(s->w_stats.p, 0, ST_COUNT * sizeof(unsigned long long)));
     s->uploaded = true;
@@ -318,7 +336,9 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
     if ((rc = s->w_vP.ensure(cap_paths))) return rc;
     if ((rc = s->w_vN.ensure(cap_paths))) return rc;
     if ((rc = s->w_rng.ensure(cap_paths))) return rc;
-    if ((rc = s->w_contrib.ensure(cap_paths * (nlL ? nlL : 1)))) return rc;
+    const bool in_wave = nlL > 0 && nlL <= 64 && (64 % nlL) == 0;
+    if (!in_wave && (rc = s->w_contrib.ensure(cap_paths * (nlL ? nlL : 1)))) return rc;
+    if ((rc = s->w_direct.ensure(cap_paths))) return rc;
     if ((rc = s->w_stackA.ensure(cap_paths * (P.bounces ? P.bounces : 1)))) return rc;
     if ((rc = s->w_stackB.ensure(cap_paths * (P.bounces ? P.bounces : 1)))) return rc;
     if ((rc = s->w_radiance.ensure(cap_paths))) return rc;
@@ -334,7 +354,7 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
     pc.counts = s->w_counts.p;
     for (int q = 0; q < 2; ++q) { pc.ray_o[q] = s->w_ray_o[q].p; pc.ray_d[q] = s->w_ray_d[q].p; }
     pc.hit_id = s->w_hit_id.p; pc.hit_t = s->w_hit_t.p;
-    pc.vP = s->w_vP.p; pc.vN = s->w_vN.p; pc.rng = s->w_rng.p; pc.contrib = s->w_contrib.p;
+    pc.vP = s->w_vP.p; pc.vN = s->w_vN.p; pc.rng = s->w_rng.p; pc.contrib = s->w_contrib.p; pc.direct = s->w_direct.p; pc.in_wave = in_wave ? 1u : 0u;
     pc.stackA = s->w_stackA.p; pc.stackB = s->w_stackB.p; pc.radiance = s->w_radiance.p; pc.accum = s->w_accum.p;
     pc.jump = s->w_jump.p; pc.stats = s->w_stats.p; pc.rgba = rgba_dev;
 
@@ -465,7 +485,7 @@ int rt_scene_create(const float* tri_pos, const float* tri_nrm, const uint32_t* 
     *out = nullptr;
     if ((n_tri && (!tri_pos || !tri_nrm || !tri_mat)) || (n_sph && (!sph || !sph_mat)) || ((n_tri || n_sph) && (!mats || !n_mat)))
         return fail(RT_ERR_INVALID, "NULL array with a non-zero count");
-    if ((uint64_t)n_tri + n_sph >= (1ull << 31)) return fail(RT_ERR_LIMIT, "more than 2^31 objects");
+    if ((uint64_t)n_tri + n_sph >= (1ull << 30)) return fail(RT_ERR_LIMIT, "more than 2^30 objects");
     for (uint32_t i = 0; i < n_tri; ++i)
         if (tri_mat[i] >= n_mat) return fail(RT_ERR_INVALID, "triangle material index out of range");
     for (uint32_t i = 0; i < n_sph; ++i)
@@ -491,7 +511,7 @@ void rt_scene_destroy(rt_scene* s) {
     s->d_sph_aux.release(); s->d_lights.release(); s->d_ovf.release();
     s->w_counts.release(); s->w_hit_id.release(); s->w_hit_t.release();
     for (int q = 0; q < 2; ++q) { s->w_ray_o[q].release(); s->w_ray_d[q].release(); }
-    s->w_vP.release(); s->w_vN.release(); s->w_contrib.release(); s->w_stackA.release(); s->w_stackB.release();
+    s->w_vP.release(); s->w_vN.release(); s->w_contrib.release(); s->w_direct.release(); s->w_stackA.release(); s->w_stackB.release();
     s->w_radiance.release(); s->w_accum.release(); s->w_rng.release(); s->w_jump.release(); s->w_stats.release();
     s->w_frame.release(); s->w_ids.release(); s->w_ts.release(); s->w_rays.release();
     for (size_t i = 0; i < s->events.size(); ++i) { (void)hipEventDestroy(s->events[i].a); (void)hipEventDestroy(s->events[i].b); }
@@ -623,6 +643,7 @@ int rt_set_option(rt_scene* s, const char* name, uint64_t value) {
     if (n == "stats") s->opt_stats = value != 0;
     else if (n == "timing") s->opt_timing = value != 0;
     else if (n == "max_paths") s->opt_max_paths = value ? value : (1ull << 22);
+    else if (n == "inner_min") { s->opt_inner_min = value > 64 ? 64 : (uint32_t)value; s->dev.inner_min = s->opt_inner_min; }
     else return fail(RT_ERR_INVALID, "unknown option '" + n + "'");
     return RT_OK;
 }

@@ -4,8 +4,8 @@
 // bounces - k, src/raytracer.rs:330-350) the host enqueues
 //   k_extend   closest-hit BVH traversal over the live ray queue      (Scene::intersect, mod.rs:406-447)
 //   k_shade_a  hit point + shading normal, terminates misses / depth 0 (mod.rs:58-67, raytracer.rs:339)
-//   k_shadow   one thread per (vertex, light, light sample): sample_l + any-hit traversal
-//                                                                      (objects.rs:96-118, mod.rs:452-491)
+//   k_shadow   one thread per (vertex, light, light sample): sample_l + any-hit traversal + ordered
+//              in-wave sum of the vertex's samples                     (objects.rs:96-118, mod.rs:452-491)
 //   k_shade_b  ordered sum of the light samples, emission, Russian roulette, BSDF sample, and
 //              wave64 ballot compaction of the surviving paths into the next ray queue
 //                                                                      (raytracer.rs:251-326)
@@ -42,6 +42,7 @@ struct DevScene {
     uint32_t n_tri, n_sph, n_lights, root;
     uint32_t* ovf;           // traversal-stack overflow rows beyond RT_STACK_LDS: [row][global thread]
     uint32_t ovf_stride;
+    uint32_t inner_min;      // traverse(): leaf tests start when fewer lanes than this are still at inner nodes
 };
 
 struct TravStats {
@@ -63,7 +64,9 @@ struct PassCtx {
     float4* vP;                      // (hit point, material index bits)
     float4* vN;                      // (shading normal, alive flag)
     uint64_t* rng;                   // per path slot
-    float4* contrib;                 // per (vertex, light sample): (rgb, visible)
+    float4* contrib;                 // per (vertex, light sample): (rgb, visible); only when !in_wave
+    float4* direct;                  // per vertex: light-sample sum (in_wave)
+    uint32_t in_wave;                // nlL divides 64: k_shadow sums a vertex's light samples inside the wave
     float4* stackA;                  // [level][slot] (direct rgb, cos)
     float4* stackB;                  // [level][slot] (reflected rgb, pdf)
     float4* radiance;                // per path slot: finished sample
@@ -183,116 +186,101 @@ struct Stack {
 // rounded differently; the slack keeps the winner identical to the reference's unpruned search.
 __device__ __forceinline__ float prune_limit(float t) { return t + fmaxf(fabsf(t), 1.0f) * (1.0f / 1024.0f); }
 
-// Scene::intersect (src/scene/mod.rs:406-447).  The reference visits every leaf whose ancestors'
-// boxes the ray passes, in DFS order with the right child first, and keeps the first strictly
-// smallest distance.  Here: near child first, far child pushed, subtrees beyond the best distance
-// skipped, and equal distances resolved by the leaf's rank in the reference's visiting order —
-// the same (object, distance).
-template <bool STATS>
-__device__ __forceinline__ void closest_hit(const DevScene& sc, vec3 o, vec3 d, Stack& st, uint32_t* out_id, float* out_t, TravStats* ts) {
+// BVH traversal, one ray per lane, executed by the whole wave in step ("while-while"): lanes walk
+// inner nodes until fewer than sc.inner_min of them are still at an inner node while others wait at a
+// leaf, then the waiting lanes run their primitive test together.  Keeping the two code blocks apart
+// keeps most of the 64 lanes active in each (the alternative, one if/else per step, ran at 45-49 %
+// VALU lane utilisation: profiles/r01_*).
+//
+// KIND 0, Scene::intersect (src/scene/mod.rs:406-447): the reference visits every leaf whose
+//   ancestors' boxes the ray passes, in DFS order with the right child first, and keeps the first
+//   strictly smallest distance.  Here: nearer child first, farther child pushed, subtrees beyond the
+//   best distance skipped, equal distances resolved by the leaf's rank in the reference's visiting
+//   order — the same (object, distance).
+// KIND 1, Scene::is_occluded (src/scene/mod.rs:452-491): true iff some visited leaf reports
+//   0 < d < max_dist on a non-emissive object.  Order-independent, so subtrees entered beyond
+//   max_dist are skipped, emissive leaves (which can never block, mod.rs:481) are not tested, and the
+//   first blocker ends the ray.
+// Lanes with have_ray == false take part in the wave votes only.
+template <int KIND, bool STATS>
+__device__ __forceinline__ void traverse(const DevScene& sc, bool have_ray, vec3 o, vec3 d, float max_dist, Stack& st, uint32_t* out_id,
+                                         float* out_t, bool* out_occluded, TravStats* ts) {
     const BoxRay br = make_box_ray(o, d);
-    float best = __builtin_inff();
+    float best = KIND == 0 ? __builtin_inff() : max_dist;
+    const float lim_any = prune_limit(max_dist);
     uint32_t best_id = RT_MISS, best_rank = 0xFFFFFFFFu;
+    bool occluded = false;
     st.sp = 0;
     uint32_t cur = sc.root;
-    if (sc.n_tri + sc.n_sph == 0) { *out_id = RT_MISS; *out_t = best; return; }
+    bool done = !have_ray || (sc.n_tri + sc.n_sph == 0);
+    const uint32_t inner_min = sc.inner_min;
     for (;;) {
-        if (!(cur & LEAF_BIT)) {
-            const float4* n = sc.nodes + 4 * (size_t)cur;
-            const float4 a = n[0], b = n[1], c = n[2], k = n[3];
-            if (STATS) ts->inner++;
-            float tl, tr;
-            bool hl = slab(br, a.x, a.y, a.z, a.w, b.x, b.y, &tl);
-            bool hr = slab(br, b.z, b.w, c.x, c.y, c.z, c.w, &tr);
-            const float lim = prune_limit(best);
-            hl = hl && !(tl > lim);
-            hr = hr && !(tr > lim);
-            const uint32_t left = __float_as_uint(k.x), right = __float_as_uint(k.y);
-            if (hl && hr) {
-                const bool left_first = !(tr < tl);
-                st.push(left_first ? right : left);
-                cur = left_first ? left : right;
-                continue;
-            }
-            if (hl) { cur = left; continue; }
-            if (hr) { cur = right; continue; }
-        } else {
-            const uint32_t obj = cur & ~LEAF_BIT;
-            float t;
-            bool ok;
-            uint32_t rank;
-            if (obj < sc.n_tri) {
-                const float4* tp = sc.tris + 3 * (size_t)obj;
-                const float4 A = tp[0], B = tp[1], C = tp[2];
-                if (STATS) ts->tris++;
-                ok = hit_triangle(xyz(A), xyz(B), xyz(C), o, d, &t);
-                rank = __float_as_uint(A.w);
-            } else {
-                if (STATS) ts->sphs++;
-                ok = hit_sphere(sc.sph[obj - sc.n_tri], o, d, &t);
-                rank = sc.sph_aux[obj - sc.n_tri].x;
-            }
-            if (ok && (t < best || (t == best && best_id != RT_MISS && rank < best_rank))) {
-                best = t; best_id = obj; best_rank = rank;
+        for (;;) {
+            const bool at_inner = !done && !(cur & LEAF_BIT);
+            const unsigned long long mi = __ballot(at_inner);
+            if (!mi) break;
+            if ((uint32_t)__popcll(mi) < inner_min && __ballot(!done && (cur & LEAF_BIT)) != 0ull) break;
+            if (at_inner) {
+                const float4* n = sc.nodes + 4 * (size_t)cur;
+                const float4 a = n[0], b = n[1], c = n[2], k = n[3];
+                if (STATS) ts->inner++;
+                float tl, tr;
+                bool hl = slab(br, a.x, a.y, a.z, a.w, b.x, b.y, &tl);
+                bool hr = slab(br, b.z, b.w, c.x, c.y, c.z, c.w, &tr);
+                const float lim = KIND == 0 ? prune_limit(best) : lim_any;
+                hl = hl && !(tl > lim);
+                hr = hr && !(tr > lim);
+                const uint32_t left = __float_as_uint(k.x), right = __float_as_uint(k.y);
+                if (hl && hr) {
+                    const bool left_first = !(tr < tl);
+                    st.push(left_first ? right : left);
+                    cur = left_first ? left : right;
+                } else if (hl) {
+                    cur = left;
+                } else if (hr) {
+                    cur = right;
+                } else if (st.sp == 0) {
+                    done = true;
+                } else {
+                    cur = st.pop();
+                }
             }
         }
-        if (st.sp == 0) break;
-        cur = st.pop();
-    }
-    *out_id = best_id;
-    *out_t = best;
-}
-
-// Scene::is_occluded (src/scene/mod.rs:452-491): true iff some visited leaf reports 0 < d < max_dist
-// on a non-emissive object.  Order-independent, so subtrees entered beyond max_dist are skipped.
-template <bool STATS>
-__device__ __forceinline__ bool any_hit(const DevScene& sc, vec3 o, vec3 d, float max_dist, Stack& st, TravStats* ts) {
-    const BoxRay br = make_box_ray(o, d);
-    const float lim = prune_limit(max_dist);
-    st.sp = 0;
-    uint32_t cur = sc.root;
-    if (sc.n_tri + sc.n_sph == 0) return false;
-    for (;;) {
-        if (!(cur & LEAF_BIT)) {
-            const float4* n = sc.nodes + 4 * (size_t)cur;
-            const float4 a = n[0], b = n[1], c = n[2], k = n[3];
-            if (STATS) ts->inner++;
-            float tl, tr;
-            bool hl = slab(br, a.x, a.y, a.z, a.w, b.x, b.y, &tl);
-            bool hr = slab(br, b.z, b.w, c.x, c.y, c.z, c.w, &tr);
-            hl = hl && !(tl > lim);
-            hr = hr && !(tr > lim);
-            const uint32_t left = __float_as_uint(k.x), right = __float_as_uint(k.y);
-            if (hl && hr) {
-                const bool left_first = !(tr < tl);
-                st.push(left_first ? right : left);
-                cur = left_first ? left : right;
-                continue;
+        if (!done && (cur & LEAF_BIT)) {
+            if (KIND == 0 || !(cur & NONBLOCK_BIT)) {
+                const uint32_t obj = cur & OBJECT_MASK;
+                float t;
+                bool ok;
+                uint32_t rank;
+                if (obj < sc.n_tri) {
+                    const float4* tp = sc.tris + 3 * (size_t)obj;
+                    const float4 A = tp[0], B = tp[1], C = tp[2];
+                    if (STATS) ts->tris++;
+                    ok = hit_triangle(xyz(A), xyz(B), xyz(C), o, d, &t);
+                    rank = __float_as_uint(A.w);
+                } else {
+                    if (STATS) ts->sphs++;
+                    ok = hit_sphere(sc.sph[obj - sc.n_tri], o, d, &t);
+                    rank = KIND == 0 ? sc.sph_aux[obj - sc.n_tri].x : 0u;
+                }
+                if (KIND == 0) {
+                    if (ok && (t < best || (t == best && best_id != RT_MISS && rank < best_rank))) {
+                        best = t; best_id = obj; best_rank = rank;
+                    }
+                } else if (ok && t > 0.0f && t < best) {
+                    occluded = true;
+                    done = true;
+                }
             }
-            if (hl) { cur = left; continue; }
-            if (hr) { cur = right; continue; }
-        } else {
-            const uint32_t obj = cur & ~LEAF_BIT;
-            float t;
-            bool ok;
-            uint32_t info;
-            if (obj < sc.n_tri) {
-                const float4* tp = sc.tris + 3 * (size_t)obj;
-                const float4 A = tp[0], B = tp[1], C = tp[2];
-                if (STATS) ts->tris++;
-                ok = hit_triangle(xyz(A), xyz(B), xyz(C), o, d, &t);
-                info = __float_as_uint(B.w);
-            } else {
-                if (STATS) ts->sphs++;
-                ok = hit_sphere(sc.sph[obj - sc.n_tri], o, d, &t);
-                info = sc.sph_aux[obj - sc.n_tri].y;
+            if (!done) {
+                if (st.sp == 0) done = true;
+                else cur = st.pop();
             }
-            if (ok && t > 0.0f && t < max_dist && (info & RT_INFO_BLOCKER)) return true;
         }
-        if (st.sp == 0) break;
-        cur = st.pop();
+        if (__ballot(!done) == 0ull) break;
     }
-    return false;
+    if (KIND == 0) { *out_id = best_id; *out_t = best; }
+    else *out_occluded = occluded;
 }
 
 __device__ __forceinline__ uint32_t object_info(const DevScene& sc, uint32_t obj) {
@@ -414,11 +402,12 @@ __global__ void __launch_bounds__(RT_BLOCK) k_primary(DevScene sc, rt_render_par
     const vec3 cam = mk(P.cam[0], P.cam[1], P.cam[2]);
     for (uint32_t op = blockIdx.x * RT_BLOCK + threadIdx.x; op < n_own_pixels; op += gridDim.x * RT_BLOCK) {
         uint32_t x, y;
-        if (!own_pixel_xy(P, tiles_x, op, &x, &y)) continue;
+        const bool valid = own_pixel_xy(P, tiles_x, op, &x, &y);
         const vec3 d = screen_to_world(P, x, y);
         uint32_t id;
         float t;
-        closest_hit<STATS>(sc, cam, d, st, &id, &t, &tst);
+        traverse<0, STATS>(sc, valid, cam, d, 0.0f, st, &id, &t, nullptr, &tst);
+        if (!valid) continue;
         const size_t pi = (size_t)y * P.width + x;
         if (ids) ids[pi] = id;
         if (ts_out) ts_out[pi] = t;
@@ -464,7 +453,7 @@ __global__ void __launch_bounds__(RT_BLOCK, 8) k_extend(DevScene sc, PassCtx pc,
     for (uint32_t e = blockIdx.x * RT_BLOCK + threadIdx.x; e < n; e += gridDim.x * RT_BLOCK) {
         uint32_t id;
         float t;
-        closest_hit<STATS>(sc, xyz(ro[e]), xyz(rd[e]), st, &id, &t, &tst);
+        traverse<0, STATS>(sc, true, xyz(ro[e]), xyz(rd[e]), 0.0f, st, &id, &t, nullptr, &tst);
         pc.hit_id[e] = id;
         pc.hit_t[e] = t;
     }
@@ -513,7 +502,12 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_a(DevScene sc, PassCtx pc, u
 }
 
 // One thread per (vertex, light, light sample) of one_bounce_radiance_importance
-// (src/raytracer.rs:266-281): Object::sample_l (objects.rs:101-116) + the shadow ray.
+// (src/raytracer.rs:266-283): Object::sample_l (objects.rs:101-116), the shadow ray, and the
+// contribution Le * bsdf * |wi.n| * pdf.  Ray r = e * nlL + j: the nlL rays of a vertex sit in
+// neighbouring lanes (same origin, same light), so their traversals stay coherent at every level.
+// When nlL divides 64 (pc.in_wave) the light samples of a vertex are summed right here, in sample
+// order, by the vertex's first lane reading the wave's results back from LDS, and only the direct
+// term (16 B per vertex) goes to HBM; otherwise each sample goes to pc.contrib for k_shade_b.
 // HEMI = the hemisphere direct-lighting estimator (not in the reference source).
 template <bool STATS, bool HEMI>
 __global__ void __launch_bounds__(RT_BLOCK, 8) k_shadow(DevScene sc, PassCtx pc, uint32_t level) {
@@ -522,48 +516,82 @@ __global__ void __launch_bounds__(RT_BLOCK, 8) k_shadow(DevScene sc, PassCtx pc,
     const uint32_t n = pc.counts[level] * pc.nlL;
     const float4* ro = pc.ray_o[level & 1];
     const uint32_t L = pc.P.light_samples;
+    uint32_t* red = s_stack;   // rows 0..3 of this wave's own (then empty) stack columns: red[k * RT_BLOCK + thread] = component k
     for (uint32_t r = blockIdx.x * RT_BLOCK + threadIdx.x; r < n; r += gridDim.x * RT_BLOCK) {
         const uint32_t e = r / pc.nlL, j = r - e * pc.nlL;
         const float4 N4 = pc.vN[e];
-        if (N4.w == 0.0f) continue;
+        const bool alive = N4.w != 0.0f;
         const float4 P4 = pc.vP[e];
-        const uint32_t slot = __float_as_uint(ro[e].w);
-        const ulonglong2 jm = pc.jump[j];
-        uint64_t rng = jm.x * pc.rng[slot] + jm.y;
         const vec3 p = xyz(P4), nrm = xyz(N4);
-        const float4 m0 = sc.mats[2 * __float_as_uint(P4.w)];
-        // Object::bsdf, objects.rs:121-127
-        const vec3 reflected = __float_as_uint(m0.x) == RT_BSDF_DIFFUSE ? scale(mk(m0.y, m0.z, m0.w), 1.0f / RT_PI) : mk(0.0f, 0.0f, 0.0f);
         float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (!HEMI) {
-            const uint32_t light = sc.lights[j / L];
-            const float4 cr = sc.sph[light - sc.n_tri];
-            const vec3 le = xyz(sc.mats[2 * (sc.sph_aux[light - sc.n_tri].y & ~RT_INFO_BLOCKER) + 1]);
-            const vec3 s = add(xyz(cr), scale(random_sphere(&rng), cr.w));          // Sphere::random_point, objects.rs:223-226
-            const vec3 ps = sub(s, p);
-            const float d_s = length3(ps);
-            const vec3 wi = scale(ps, 1.0f / d_s);
-            const float d_c = length3(sub(xyz(cr), p));
-            const float cos_a = (d_c * d_c + cr.w * cr.w - d_s * d_s) / (2.0f * d_c * cr.w);
-            const float pdf = 2.0f * RT_PI * (1.0f - cos_a);
-            if (!any_hit<STATS>(sc, p, wi, d_s, st, &tst)) {
-                const float cos_theta = fabsf(dot3(wi, nrm));
-                const vec3 c = scale(scale(mul3(le, reflected), cos_theta), pdf);   // raytracer.rs:279
-                out = make_float4(c.x, c.y, c.z, 1.0f);
-            }
-        } else {
-            const vec3 wi = to_coord_space(random_hemisphere(&rng), nrm);
-            uint32_t id;
-            float t;
-            closest_hit<STATS>(sc, p, unit3(wi), st, &id, &t, &tst);
-            if (id != RT_MISS) {
-                const vec3 le = xyz(sc.mats[2 * (object_info(sc, id) & ~RT_INFO_BLOCKER) + 1]);
-                const float cos_theta = fabsf(dot3(wi, nrm));
-                const vec3 c = scale(scale(mul3(le, reflected), cos_theta), 2.0f * RT_PI);
-                out = make_float4(c.x, c.y, c.z, 1.0f);
+        vec3 wi = mk(0.0f, 0.0f, 1.0f), c = mk(0.0f, 0.0f, 0.0f), reflected = mk(0.0f, 0.0f, 0.0f);
+        float d_s = 0.0f, cos_theta = 0.0f;
+        if (alive) {
+            const uint32_t slot = __float_as_uint(ro[e].w);
+            const ulonglong2 jm = pc.jump[j];
+            uint64_t rng = jm.x * pc.rng[slot] + jm.y;
+            const float4 m0 = sc.mats[2 * __float_as_uint(P4.w)];
+            // Object::bsdf, objects.rs:121-127
+            reflected = __float_as_uint(m0.x) == RT_BSDF_DIFFUSE ? scale(mk(m0.y, m0.z, m0.w), 1.0f / RT_PI) : mk(0.0f, 0.0f, 0.0f);
+            if (!HEMI) {
+                const uint32_t light = sc.lights[j / L];
+                const float4 cr = sc.sph[light - sc.n_tri];
+                const vec3 le = xyz(sc.mats[2 * (sc.sph_aux[light - sc.n_tri].y & ~RT_INFO_BLOCKER) + 1]);
+                const vec3 s = add(xyz(cr), scale(random_sphere(&rng), cr.w));      // Sphere::random_point, objects.rs:223-226
+                const vec3 ps = sub(s, p);
+                d_s = length3(ps);
+                wi = scale(ps, 1.0f / d_s);
+                const float d_c = length3(sub(xyz(cr), p));
+                const float cos_a = (d_c * d_c + cr.w * cr.w - d_s * d_s) / (2.0f * d_c * cr.w);
+                const float pdf = 2.0f * RT_PI * (1.0f - cos_a);
+                cos_theta = fabsf(dot3(wi, nrm));
+                c = scale(scale(mul3(le, reflected), cos_theta), pdf);              // raytracer.rs:279
+            } else {
+                const vec3 w = to_coord_space(random_hemisphere(&rng), nrm);
+                cos_theta = fabsf(dot3(w, nrm));
+                wi = unit3(w);
             }
         }
-        pc.contrib[r] = out;
+        if (!HEMI) {
+            bool occluded = false;
+            traverse<1, STATS>(sc, alive, p, wi, d_s, st, nullptr, nullptr, &occluded, &tst);
+            if (alive && !occluded) out = make_float4(c.x, c.y, c.z, 1.0f);
+        } else {
+            uint32_t id = RT_MISS;
+            float t;
+            traverse<0, STATS>(sc, alive, p, wi, 0.0f, st, &id, &t, nullptr, &tst);
+            if (alive && id != RT_MISS) {
+                const vec3 le = xyz(sc.mats[2 * (object_info(sc, id) & ~RT_INFO_BLOCKER) + 1]);
+                const vec3 ch = scale(scale(mul3(le, reflected), cos_theta), 2.0f * RT_PI);
+                out = make_float4(ch.x, ch.y, ch.z, 1.0f);
+            }
+        }
+        if (!pc.in_wave) {
+            pc.contrib[r] = out;
+            continue;
+        }
+        // ordered sum over the vertex's samples (raytracer.rs:269-283): color += ...; l += color / L
+        red[threadIdx.x] = __float_as_uint(out.x);
+        red[RT_BLOCK + threadIdx.x] = __float_as_uint(out.y);
+        red[2 * RT_BLOCK + threadIdx.x] = __float_as_uint(out.z);
+        red[3 * RT_BLOCK + threadIdx.x] = __float_as_uint(out.w);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (j == 0 && alive) {
+            const float inv_light_samples = 1.0f / (float)L;
+            vec3 l = mk(0.0f, 0.0f, 0.0f);
+            for (uint32_t g = 0; g < pc.n_groups; ++g) {
+                vec3 color = mk(0.0f, 0.0f, 0.0f);
+                for (uint32_t s = 0; s < L; ++s) {
+                    const uint32_t src = threadIdx.x + g * L + s;            // a lane of this wave: j == 0 and nlL | 64
+                    if (red[3 * RT_BLOCK + src] != 0u)
+                        color = add(color, mk(__uint_as_float(red[src]), __uint_as_float(red[RT_BLOCK + src]), __uint_as_float(red[2 * RT_BLOCK + src])));
+                }
+                l = add(l, scale(color, inv_light_samples));
+            }
+            pc.direct[e] = make_float4(l.x, l.y, l.z, 0.0f);
+        }
+        __builtin_amdgcn_wave_barrier();
     }
     flush_stats<STATS>(pc.stats, tst, HEMI ? ST_C_INNER : ST_S_INNER);
 }
@@ -592,14 +620,18 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_b(DevScene sc, PassCtx pc, u
                 const float4 m0 = sc.mats[2 * mat], m1 = sc.mats[2 * mat + 1];
                 const vec3 p = xyz(P4), nrm = xyz(N4);
                 vec3 l = mk(0.0f, 0.0f, 0.0f);
-                const float4* cp = pc.contrib + (size_t)e * pc.nlL;
-                for (uint32_t g = 0; g < pc.n_groups; ++g) {
-                    vec3 color = mk(0.0f, 0.0f, 0.0f);
-                    for (uint32_t s = 0; s < L; ++s) {
-                        const float4 c = cp[g * L + s];
-                        if (c.w != 0.0f) color = add(color, xyz(c));
+                if (pc.in_wave) {
+                    l = xyz(pc.direct[e]);                                          // summed by k_shadow
+                } else {
+                    const float4* cp = pc.contrib + (size_t)e * pc.nlL;
+                    for (uint32_t g = 0; g < pc.n_groups; ++g) {
+                        vec3 color = mk(0.0f, 0.0f, 0.0f);
+                        for (uint32_t s = 0; s < L; ++s) {
+                            const float4 c = cp[g * L + s];
+                            if (c.w != 0.0f) color = add(color, xyz(c));
+                        }
+                        l = add(l, scale(color, inv_light_samples));                // raytracer.rs:282
                     }
-                    l = add(l, scale(color, inv_light_samples));                    // raytracer.rs:282
                 }
                 l = add(l, xyz(m1));                                                // raytracer.rs:284
                 if (bounces_left == 1) {
@@ -668,7 +700,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_rays_closest(DevScene sc, const fl
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
         uint32_t id;
         float t;
-        closest_hit<false>(sc, mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]), mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), st, &id, &t, &tst);
+        traverse<0, false>(sc, true, mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]), mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), 0.0f, st, &id, &t, nullptr, &tst);
         ids[i] = id;
         ts_out[i] = t;
     }
@@ -676,8 +708,12 @@ __global__ void __launch_bounds__(RT_BLOCK) k_rays_closest(DevScene sc, const fl
 __global__ void __launch_bounds__(RT_BLOCK) k_rays_occluded(DevScene sc, const float* org, const float* dir, const float* maxd, uint32_t n, uint8_t* out) {
     RT_STACK_DECL;
     TravStats tst = {0, 0, 0};
-    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK)
-        out[i] = any_hit<false>(sc, mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]), mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), maxd[i], st, &tst) ? 1 : 0;
+    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
+        bool occ = false;
+        traverse<1, false>(sc, true, mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]), mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), maxd[i], st, nullptr,
+                           nullptr, &occ, &tst);
+        out[i] = occ ? 1 : 0;
+    }
 }
 
 // Screen-tile pack / unpack for the multi-GPU gather.  words = bytes_per_pixel / 4.
