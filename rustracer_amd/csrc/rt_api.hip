@@ -82,7 +82,7 @@ struct rt_scene {
 
     bool opt_stats = false, opt_timing = false;
     uint64_t opt_max_paths = 1ull << 22;
-    uint32_t opt_inner_min = 12;
+    uint32_t opt_inner_min = 12, opt_self_test = 1;
     uint32_t grid_max = 2048;
 
     std::vector<EventPair> events;
@@ -137,13 +137,12 @@ int upload_scene(rt_scene* s) {
         const float* p = &h.tri_pos[9 * (size_t)i];
         const float* n = &h.tri_nrm[9 * (size_t)i];
         const vec3 p1 = mk(p[0], p[1], p[2]), p2 = mk(p[3], p[4], p[5]), p3 = mk(p[6], p[7], p[8]);
-        const vec3 e1 = sub(p2, p1), e2 = sub(p3, p1);
         const rt_material& m = h.mats[h.tri_mat[i]];
         const bool emissive = !scene_is_black(m.emittance);
         const uint32_t info = h.tri_mat[i] | (emissive ? 0u : RT_INFO_BLOCKER);
         tris[3 * (size_t)i] = make_float4(p1.x, p1.y, p1.z, bits_to_float(b.rank[i]));
-        tris[3 * (size_t)i + 1] = make_float4(e1.x, e1.y, e1.z, bits_to_float(info));
-        tris[3 * (size_t)i + 2] = make_float4(e2.x, e2.y, e2.z, 0.0f);
+        tris[3 * (size_t)i + 1] = make_float4(p2.x, p2.y, p2.z, bits_to_float(info));
+        tris[3 * (size_t)i + 2] = make_float4(p3.x, p3.y, p3.z, 0.0f);
         for (int k = 0; k < 3; ++k) nrm[3 * (size_t)i + k] = make_float4(n[3 * k], n[3 * k + 1], n[3 * k + 2], 0.0f);
     }
     for (uint32_t i = 0; i < S; ++i) {
@@ -199,7 +198,7 @@ int upload_scene(rt_scene* s) {
         if (!scene_is_black(m.emittance)) d.root |= NONBLOCK_BIT;
     }
     d.ovf = s->d_ovf.p; d.ovf_stride = s->grid_max * RT_BLOCK;
-    d.inner_min = s->opt_inner_min;
+    d.inner_min = s->opt_inner_min; d.self_test = s->opt_self_test;
     if ((rc = s->w_stats.ensure(ST_COUNT))) return rc;
     HIP_TRY(hipMemset(s->w_stats.p, 0, ST_COUNT * sizeof(unsigned long long)));
     s->uploaded = true;
@@ -643,6 +642,7 @@ int rt_set_option(rt_scene* s, const char* name, uint64_t value) {
     if (n == "stats") s->opt_stats = value != 0;
     else if (n == "timing") s->opt_timing = value != 0;
     else if (n == "max_paths") s->opt_max_paths = value ? value : (1ull << 22);
+    else if (n == "self_test") { s->opt_self_test = value ? 1 : 0; s->dev.self_test = s->opt_self_test; }
     else if (n == "inner_min") { s->opt_inner_min = value > 64 ? 64 : (uint32_t)value; s->dev.inner_min = s->opt_inner_min; }
     else return fail(RT_ERR_INVALID, "unknown option '" + n + "'");
     return RT_OK;

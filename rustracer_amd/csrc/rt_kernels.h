@@ -33,7 +33,7 @@ namespace rt {
 
 struct DevScene {
     const float4* nodes;     // 4 x float4 per inner node (64 B)
-    const float4* tris;      // 3 x float4 per triangle (48 B): (p1, rank) (e1, info) (e2, 0)
+    const float4* tris;      // 3 x float4 per triangle (48 B): (p1, rank) (p2, info) (p3, 0)
     const float4* tri_nrm;   // 3 x float4 per triangle (48 B): vn1, vn2, vn3
     const float4* sph;       // (center, radius)
     const uint2* sph_aux;    // (rank, info)
@@ -42,6 +42,7 @@ struct DevScene {
     uint32_t n_tri, n_sph, n_lights, root;
     uint32_t* ovf;           // traversal-stack overflow rows beyond RT_STACK_LDS: [row][global thread]
     uint32_t ovf_stride;
+    uint32_t self_test;      // shadow rays test the object they start on first
     uint32_t inner_min;      // traverse(): leaf tests start when fewer lanes than this are still at inner nodes
 };
 
@@ -62,7 +63,7 @@ struct PassCtx {
     uint32_t* hit_id;
     float* hit_t;
     float4* vP;                      // (hit point, material index bits)
-    float4* vN;                      // (shading normal, alive flag)
+    float4* vN;                      // (shading normal, bits: hit object id + 1, 0 = path ended)
     uint64_t* rng;                   // per path slot
     float4* contrib;                 // per (vertex, light sample): (rgb, visible); only when !in_wave
     float4* direct;                  // per vertex: light-sample sum (in_wave)
@@ -135,8 +136,10 @@ __device__ __forceinline__ bool slab(const BoxRay& r, float mnx, float mny, floa
     return !miss && (ray_max > 0.0f);
 }
 
-// Object::intersect, triangle arm (src/scene/objects.rs:38-57); e1 = p2-p1 and e2 = p3-p1 are stored.
-__device__ __forceinline__ bool hit_triangle(vec3 p1, vec3 e1, vec3 e2, vec3 o, vec3 d, float* t_out) {
+// Object::intersect, triangle arm (src/scene/objects.rs:38-57).
+__device__ __forceinline__ bool hit_triangle(vec3 p1, vec3 p2, vec3 p3, vec3 o, vec3 d, float* t_out) {
+    const vec3 e1 = sub(p2, p1);
+    const vec3 e2 = sub(p3, p1);
     const vec3 s = sub(o, p1);
     const vec3 s1 = cross3(d, e2);
     const vec3 s2 = cross3(s, e1);
@@ -177,9 +180,20 @@ struct Stack {
     }
     __device__ __forceinline__ uint32_t pop() {
         --sp;
-        return sp < RT_STACK_LDS ? lds[sp * RT_BLOCK] : ovf[(size_t)(sp - RT_STACK_LDS) * ovf_stride];
+        uint32_t v;
+        if (sp < RT_STACK_LDS) {
+            v = lds[sp * RT_BLOCK];
+        } else {
+            v = ovf[(size_t)(sp - RT_STACK_LDS) * ovf_stride];
+            asm volatile("" : "+v"(v));   // keeps the two loads apart: merged, they become one flat_load through a generic pointer
+        }
+        return v;
     }
 };
+
+// Leaf box of a triangle exactly as the host builder forms it (Bounded for Triangle, objects.rs:302-316).
+__device__ __forceinline__ float lo3(float a, float b, float c) { const float m = a < b ? a : b; return m < c ? m : c; }
+__device__ __forceinline__ float hi3(float a, float b, float c) { const float m = a > b ? a : b; return m > c ? m : c; }
 
 // Pruning slack: a subtree is skipped only when its entry distance exceeds the current limit by
 // more than 2^-10 relative (absolute below 1).  The primitive's own t and the box entry are
@@ -203,8 +217,8 @@ __device__ __forceinline__ float prune_limit(float t) { return t + fmaxf(fabsf(t
 //   first blocker ends the ray.
 // Lanes with have_ray == false take part in the wave votes only.
 template <int KIND, bool STATS>
-__device__ __forceinline__ void traverse(const DevScene& sc, bool have_ray, vec3 o, vec3 d, float max_dist, Stack& st, uint32_t* out_id,
-                                         float* out_t, bool* out_occluded, TravStats* ts) {
+__device__ __forceinline__ void traverse(const DevScene& sc, bool have_ray, vec3 o, vec3 d, float max_dist, uint32_t self_obj, Stack& st,
+                                         uint32_t* out_id, float* out_t, bool* out_occluded, TravStats* ts) {
     const BoxRay br = make_box_ray(o, d);
     float best = KIND == 0 ? __builtin_inff() : max_dist;
     const float lim_any = prune_limit(max_dist);
@@ -214,6 +228,37 @@ __device__ __forceinline__ void traverse(const DevScene& sc, bool have_ray, vec3
     uint32_t cur = sc.root;
     bool done = !have_ray || (sc.n_tri + sc.n_sph == 0);
     const uint32_t inner_min = sc.inner_min;
+    if (KIND == 1 && !done && self_obj != RT_MISS) {
+        // Shadow rays start on the surface the path just hit, and about half of them are blocked by that very
+        // object at t ~ 1e-6 (the reference applies no surface offset: mod.rs:58-62).  Test it first.  This is
+        // the reference's result, not an approximation: a leaf is reached iff the ray passes the boxes of all
+        // its ancestors, and with finite 1/d every step of the slab test is monotone in the box bounds while
+        // each ancestor's box contains the leaf's, so "reached" == "passes the leaf's own box" (same floats as
+        // the host builder: min/max of the stored vertices, centre -+ radius).  Rays with a non-finite 1/d
+        // (0 * inf = NaN in the slab test) skip this and take the full traversal.
+        const float fin = br.ix - br.ix + (br.iy - br.iy) + (br.iz - br.iz);   // 0 if all finite, NaN otherwise
+        if (fin == 0.0f) {
+            float t, tn;
+            bool ok = false;
+            if (self_obj < sc.n_tri) {
+                const float4* tp = sc.tris + 3 * (size_t)self_obj;
+                const float4 A = tp[0], B = tp[1], C = tp[2];
+                if (__float_as_uint(B.w) & RT_INFO_BLOCKER) {
+                    if (STATS) ts->tris++;
+                    const float mnx = lo3(A.x, B.x, C.x), mny = lo3(A.y, B.y, C.y), mnz = lo3(A.z, B.z, C.z);
+                    const float mxx = hi3(A.x, B.x, C.x), mxy = hi3(A.y, B.y, C.y), mxz = hi3(A.z, B.z, C.z);
+                    ok = slab(br, mnx, mny, mnz, mxx, mxy, mxz, &tn) && hit_triangle(xyz(A), xyz(B), xyz(C), o, d, &t);
+                }
+            } else {
+                const float4 cr = sc.sph[self_obj - sc.n_tri];
+                if (sc.sph_aux[self_obj - sc.n_tri].y & RT_INFO_BLOCKER) {
+                    if (STATS) ts->sphs++;
+                    ok = slab(br, cr.x - cr.w, cr.y - cr.w, cr.z - cr.w, cr.x + cr.w, cr.y + cr.w, cr.z + cr.w, &tn) && hit_sphere(cr, o, d, &t);
+                }
+            }
+            if (ok && t > 0.0f && t < best) { occluded = true; done = true; }
+        }
+    }
     for (;;) {
         for (;;) {
             const bool at_inner = !done && !(cur & LEAF_BIT);
@@ -292,7 +337,7 @@ __device__ __forceinline__ uint32_t object_info(const DevScene& sc, uint32_t obj
 __device__ __forceinline__ vec3 surface_normal(const DevScene& sc, uint32_t obj, vec3 point) {
     if (obj >= sc.n_tri) return unit3(sub(point, xyz(sc.sph[obj - sc.n_tri])));
     const float4* tp = sc.tris + 3 * (size_t)obj;
-    const vec3 p1 = xyz(tp[0]), v0 = xyz(tp[1]), v1 = xyz(tp[2]);
+    const vec3 p1 = xyz(tp[0]), v0 = sub(xyz(tp[1]), p1), v1 = sub(xyz(tp[2]), p1);
     const vec3 v2 = sub(point, p1);
     const float d00 = dot3(v0, v0), d01 = dot3(v0, v1), d11 = dot3(v1, v1), d20 = dot3(v2, v0), d21 = dot3(v2, v1);
     const float denom = d00 * d11 - d01 * d01;
@@ -406,7 +451,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_primary(DevScene sc, rt_render_par
         const vec3 d = screen_to_world(P, x, y);
         uint32_t id;
         float t;
-        traverse<0, STATS>(sc, valid, cam, d, 0.0f, st, &id, &t, nullptr, &tst);
+        traverse<0, STATS>(sc, valid, cam, d, 0.0f, RT_MISS, st, &id, &t, nullptr, &tst);
         if (!valid) continue;
         const size_t pi = (size_t)y * P.width + x;
         if (ids) ids[pi] = id;
@@ -453,7 +498,7 @@ __global__ void __launch_bounds__(RT_BLOCK, 8) k_extend(DevScene sc, PassCtx pc,
     for (uint32_t e = blockIdx.x * RT_BLOCK + threadIdx.x; e < n; e += gridDim.x * RT_BLOCK) {
         uint32_t id;
         float t;
-        traverse<0, STATS>(sc, true, xyz(ro[e]), xyz(rd[e]), 0.0f, st, &id, &t, nullptr, &tst);
+        traverse<0, STATS>(sc, true, xyz(ro[e]), xyz(rd[e]), 0.0f, RT_MISS, st, &id, &t, nullptr, &tst);
         pc.hit_id[e] = id;
         pc.hit_t[e] = t;
     }
@@ -484,7 +529,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_a(DevScene sc, PassCtx pc, u
                 const vec3 p = add(o, scale(d, min_dist));
                 const vec3 nrm = surface_normal(sc, id, p);
                 pc.vP[e] = make_float4(p.x, p.y, p.z, __uint_as_float(mat));
-                pc.vN[e] = make_float4(nrm.x, nrm.y, nrm.z, 1.0f);
+                pc.vN[e] = make_float4(nrm.x, nrm.y, nrm.z, __uint_as_float(id + 1u));
                 alive = true;
             }
         }
@@ -520,7 +565,7 @@ __global__ void __launch_bounds__(RT_BLOCK, 8) k_shadow(DevScene sc, PassCtx pc,
     for (uint32_t r = blockIdx.x * RT_BLOCK + threadIdx.x; r < n; r += gridDim.x * RT_BLOCK) {
         const uint32_t e = r / pc.nlL, j = r - e * pc.nlL;
         const float4 N4 = pc.vN[e];
-        const bool alive = N4.w != 0.0f;
+        const bool alive = __float_as_uint(N4.w) != 0u;
         const float4 P4 = pc.vP[e];
         const vec3 p = xyz(P4), nrm = xyz(N4);
         float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -554,12 +599,12 @@ __global__ void __launch_bounds__(RT_BLOCK, 8) k_shadow(DevScene sc, PassCtx pc,
         }
         if (!HEMI) {
             bool occluded = false;
-            traverse<1, STATS>(sc, alive, p, wi, d_s, st, nullptr, nullptr, &occluded, &tst);
+            traverse<1, STATS>(sc, alive, p, wi, d_s, sc.self_test ? __float_as_uint(N4.w) - 1u : RT_MISS, st, nullptr, nullptr, &occluded, &tst);
             if (alive && !occluded) out = make_float4(c.x, c.y, c.z, 1.0f);
         } else {
             uint32_t id = RT_MISS;
             float t;
-            traverse<0, STATS>(sc, alive, p, wi, 0.0f, st, &id, &t, nullptr, &tst);
+            traverse<0, STATS>(sc, alive, p, wi, 0.0f, RT_MISS, st, &id, &t, nullptr, &tst);
             if (alive && id != RT_MISS) {
                 const vec3 le = xyz(sc.mats[2 * (object_info(sc, id) & ~RT_INFO_BLOCKER) + 1]);
                 const vec3 ch = scale(scale(mul3(le, reflected), cos_theta), 2.0f * RT_PI);
@@ -613,7 +658,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_b(DevScene sc, PassCtx pc, u
         float4 o_next = make_float4(0, 0, 0, 0), d_next = make_float4(0, 0, 0, 0);
         if (e < n) {
             const float4 N4 = pc.vN[e];
-            if (N4.w != 0.0f) {
+            if (__float_as_uint(N4.w) != 0u) {
                 const float4 P4 = pc.vP[e];
                 const uint32_t slot = __float_as_uint(ro[e].w);
                 const uint32_t mat = __float_as_uint(P4.w);
@@ -700,7 +745,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_rays_closest(DevScene sc, const fl
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
         uint32_t id;
         float t;
-        traverse<0, false>(sc, true, mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]), mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), 0.0f, st, &id, &t, nullptr, &tst);
+        traverse<0, false>(sc, true, mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]), mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), 0.0f, RT_MISS, st, &id, &t, nullptr, &tst);
         ids[i] = id;
         ts_out[i] = t;
     }
@@ -710,7 +755,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_rays_occluded(DevScene sc, const f
     TravStats tst = {0, 0, 0};
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
         bool occ = false;
-        traverse<1, false>(sc, true, mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]), mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), maxd[i], st, nullptr,
+        traverse<1, false>(sc, true, mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]), mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), maxd[i], RT_MISS, st, nullptr,
                            nullptr, &occ, &tst);
         out[i] = occ ? 1 : 0;
     }
