@@ -205,6 +205,7 @@ def cpu_baseline(a, standin, dragon_obj, target_s):
     spp = min(a.spp, 2)
 
     def run(stride):
+        nonlocal spp
         p = ob.make_params(width=a.width, height=a.height, spp=spp, light_samples=a.light_samples, bounces=a.bounces, seed=a.seed,
                            tile=(32, 32), shard=(0, stride))
         t0 = time.perf_counter()
@@ -213,12 +214,16 @@ def cpu_baseline(a, standin, dragon_obj, target_s):
         return r["intersect_calls"] + r["occluded_calls"], dt
 
     n_tiles = ((a.width + 31) // 32) * ((a.height + 31) // 32)
-    stride = max(n_tiles // 8, 1)                 # calibration: ~8 tiles
+    stride = max(n_tiles // 16, 1)                # calibration: ~16 tiles at 2 spp
     rays, dt = run(stride)
     rate = rays / max(dt, 1e-6)
-    per_tile = rays / max(n_tiles // stride, 1)
-    want_tiles = max(int(rate * target_s / max(per_tile, 1)), 8)
-    stride = max(n_tiles // want_tiles, 1)
+    per_tile_spp = rays / max(n_tiles // stride, 1) / spp
+    want_tile_spp = max(rate * target_s / max(per_tile_spp, 1), 16.0)      # (tiles x spp) that fill target_s
+    if want_tile_spp <= n_tiles * spp:
+        stride = max(int(n_tiles * spp / want_tile_spp), 1)
+    else:
+        stride = 1
+        spp = int(min(a.spp, max(spp, want_tile_spp // n_tiles)))
     rays, dt = run(stride)
     return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": "oracle (C++ restatement of the reference algorithm, %d threads): every %d-th 32x32 tile of the same %dx%d frame at %d spp, "
