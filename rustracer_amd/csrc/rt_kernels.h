@@ -399,16 +399,38 @@ __device__ __forceinline__ void fold_path(const PassCtx& pc, uint32_t slot, uint
     pc.radiance[slot] = make_float4(color.x, color.y, color.z, 0.0f);
 }
 
-// wave64 ballot + prefix compaction: one atomic per wave reserves a run in the queue.
-__device__ __forceinline__ uint32_t wave_append(bool keep, uint32_t* counter) {
-    const unsigned long long active = __ballot(1);
+// Queue compaction: wave64 ballot + prefix popcount inside each wave, the four wave totals
+// combined through LDS, and ONE atomic per workgroup and loop iteration reserves the run in the
+// queue (same-address atomics retire at roughly 10 ns each on MI355X, so one per wave made
+// k_generate / k_shade_* atomic-bound: profiles/r01_v3).  Every thread of the workgroup must call
+// it the same number of times.  s_tmp: RT_BLOCK / 64 + 1 words.
+__device__ __forceinline__ uint32_t block_append(bool keep, uint32_t* counter, uint32_t* s_tmp) {
     const unsigned long long mask = __ballot(keep);
-    const uint32_t lane = __lane_id();
-    const int leader = __ffsll((long long)active) - 1;
-    uint32_t base = 0;
-    if ((int)lane == leader && mask) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-    base = __shfl(base, leader);
+    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+    if (lane == 0) s_tmp[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < RT_BLOCK / 64; ++w) total += s_tmp[w];
+        s_tmp[RT_BLOCK / 64] = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t base = s_tmp[RT_BLOCK / 64];
+    for (uint32_t w = 0; w < wave; ++w) base += s_tmp[w];
+    __syncthreads();
     return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+// Sum of v over the workgroup, returned to thread 0 only.  s_tmp: RT_BLOCK / 64 words.
+__device__ __forceinline__ uint32_t block_sum_to_thread0(uint32_t v, uint32_t* s_tmp) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (__lane_id() == 0) s_tmp[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint32_t total = 0;
+    if (threadIdx.x == 0)
+        for (uint32_t w = 0; w < RT_BLOCK / 64; ++w) total += s_tmp[w];
+    __syncthreads();
+    return total;
 }
 
 template <bool STATS>
@@ -475,11 +497,13 @@ __global__ void __launch_bounds__(RT_BLOCK) k_primary(DevScene sc, rt_render_par
 __global__ void __launch_bounds__(RT_BLOCK) k_generate(PassCtx pc) {
     const rt_render_params& P = pc.P;
     const vec3 cam = mk(P.cam[0], P.cam[1], P.cam[2]);
-    for (uint32_t q = blockIdx.x * RT_BLOCK + threadIdx.x; q < pc.npaths; q += gridDim.x * RT_BLOCK) {
+    __shared__ uint32_t s_tmp[RT_BLOCK / 64 + 1];
+    for (uint32_t q0 = blockIdx.x * RT_BLOCK; q0 < pc.npaths; q0 += gridDim.x * RT_BLOCK) {
+        const uint32_t q = q0 + threadIdx.x;
         const uint32_t pl = q / pc.spc, s = pc.s0 + (q - pl * pc.spc);
-        uint32_t x, y;
-        const bool valid = own_pixel_xy(P, pc.tiles_x, pc.pix0 + pl, &x, &y);
-        const uint32_t e = wave_append(valid, &pc.counts[0]);
+        uint32_t x = 0, y = 0;
+        const bool valid = q < pc.npaths && own_pixel_xy(P, pc.tiles_x, pc.pix0 + pl, &x, &y);
+        const uint32_t e = block_append(valid, &pc.counts[0], s_tmp);
         if (!valid) continue;
         pc.rng[q] = stream_seed(pc.seed_mixed, y * P.width + x, s);
         const vec3 d = screen_to_world(P, x, y);
@@ -512,6 +536,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_a(DevScene sc, PassCtx pc, u
     const uint32_t bounces_left = pc.P.bounces - level;
     const float4* ro = pc.ray_o[level & 1];
     const float4* rd = pc.ray_d[level & 1];
+    __shared__ uint32_t s_tmp[RT_BLOCK / 64];
+    uint32_t n_alive = 0, n_alive_tri = 0;
     for (uint32_t e = blockIdx.x * RT_BLOCK + threadIdx.x; e < n; e += gridDim.x * RT_BLOCK) {
         const float4 o4 = ro[e];
         const uint32_t slot = __float_as_uint(o4.w);
@@ -534,15 +560,16 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_a(DevScene sc, PassCtx pc, u
             }
         }
         if (!alive) pc.vN[e] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        const unsigned long long m = __ballot(alive);
-        const unsigned long long m_tri = __ballot(alive && id < sc.n_tri);
-        const unsigned long long active = __ballot(1);
-        if ((int)__lane_id() == __ffsll((long long)active) - 1 && m) {
-            const unsigned long long rays = (unsigned long long)__popcll(m) * pc.nlL;
-            atomicAdd(&pc.stats[pc.P.direct_estimator == RT_DIRECT_HEMISPHERE ? ST_RAYS_CLOSEST : ST_RAYS_SHADOW], rays);
-            atomicAdd(&pc.stats[ST_HITS_TRI], (unsigned long long)__popcll(m_tri));
-            atomicAdd(&pc.stats[ST_HITS_SPH], (unsigned long long)__popcll(m & ~m_tri));
-        }
+        n_alive += alive ? 1u : 0u;
+        n_alive_tri += (alive && id < sc.n_tri) ? 1u : 0u;
+    }
+    // ray and hit counters: one atomic each per workgroup
+    const uint32_t t_alive = block_sum_to_thread0(n_alive, s_tmp);
+    const uint32_t t_tri = block_sum_to_thread0(n_alive_tri, s_tmp);
+    if (threadIdx.x == 0 && t_alive) {
+        atomicAdd(&pc.stats[pc.P.direct_estimator == RT_DIRECT_HEMISPHERE ? ST_RAYS_CLOSEST : ST_RAYS_SHADOW], (unsigned long long)t_alive * pc.nlL);
+        atomicAdd(&pc.stats[ST_HITS_TRI], (unsigned long long)t_tri);
+        atomicAdd(&pc.stats[ST_HITS_SPH], (unsigned long long)(t_alive - t_tri));
     }
 }
 
@@ -651,9 +678,10 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_b(DevScene sc, PassCtx pc, u
     float4* nd = pc.ray_d[(level + 1) & 1];
     const uint32_t L = pc.P.light_samples;
     const float inv_light_samples = 1.0f / (float)L;
-    // every lane of a wave runs the same number of iterations so that wave_append sees whole waves
-    const uint32_t n_round = (n + 63u) & ~63u;
-    for (uint32_t e = blockIdx.x * RT_BLOCK + threadIdx.x; e < n_round; e += gridDim.x * RT_BLOCK) {
+    // every thread of a workgroup runs the same number of iterations (block_append has barriers)
+    __shared__ uint32_t s_tmp[RT_BLOCK / 64 + 1];
+    for (uint32_t e0 = blockIdx.x * RT_BLOCK; e0 < n; e0 += gridDim.x * RT_BLOCK) {
+        const uint32_t e = e0 + threadIdx.x;
         bool cont = false;
         float4 o_next = make_float4(0, 0, 0, 0), d_next = make_float4(0, 0, 0, 0);
         if (e < n) {
@@ -712,7 +740,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_b(DevScene sc, PassCtx pc, u
                 }
             }
         }
-        const uint32_t q = wave_append(cont, &pc.counts[level + 1]);
+        const uint32_t q = block_append(cont, &pc.counts[level + 1], s_tmp);
         if (cont) { no[q] = o_next; nd[q] = d_next; }
     }
 }
