@@ -145,8 +145,10 @@ def main():
         torch.cuda.synchronize(dev)
         sc = scene.counters()
         scene.set_option("stats", 0)
-        # bytes/ray = 64*inner + 48*tri + 16*sph + 48 (ray record in, result out)
-        bytes_per_shadow_ray = (64.0 * sc["shadow_inner"] + 48.0 * sc["shadow_tris"] + 16.0 * sc["shadow_sphs"]) / max(sc["rays_shadow"], 1) + 48.0
+        # bytes/ray = 64*inner + 48*tri + 16*sph + 48 (ray record in, result out); is_occluded rays
+        # walk the 8-wide occlusion BVH, whose nodes are 80 B
+        bytes_per_shadow_ray = (80.0 * sc["shadow_wide"] + 64.0 * sc["shadow_inner"] + 48.0 * sc["shadow_tris"] + 16.0 * sc["shadow_sphs"]) \
+            / max(sc["rays_shadow"], 1) + 48.0
         bytes_per_closest_ray = (64.0 * sc["closest_inner"] + 48.0 * sc["closest_tris"] + 16.0 * sc["closest_sphs"]) / max(sc["rays_closest"], 1) + 48.0 \
             + (80.0 * sc["closest_hits_tri"] + 32.0 * sc["closest_hits_sph"]) / max(sc["rays_closest"], 1)
         launches = cnt["launches_shadow"]
@@ -156,11 +158,13 @@ def main():
         roofline = {
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": None,
-            "kernel": "k_shadow<false,false> (any-hit BVH traversal, one thread per light sample)",
+            "kernel": "k_shadow<false,false> (any-hit traversal of the 8-wide occlusion BVH, one thread per light sample)",
+            "nodes_per_ray": {"wide80B": round(sc["shadow_wide"] / max(sc["rays_shadow"], 1), 2), "binary64B": round(sc["shadow_inner"] / max(sc["rays_shadow"], 1), 2),
+                              "tri48B": round(sc["shadow_tris"] / max(sc["rays_shadow"], 1), 2)},
             "bytes_per_ray": round(bytes_per_shadow_ray, 1), "rays_per_launch": round(rays_per_launch, 1), "avg_launch_ms": round(avg_ms, 4),
             "launches_per_step": int(launches),
-            "kernel_ms_per_step": {"k_shadow": round(cnt["kernel_ms_shadow"], 2), "k_extend": round(cnt["kernel_ms_closest"], 2),
-                                   "shade+generate+resolve": round(cnt["kernel_ms_shade"], 2)},
+            "kernel_ms_per_step": {"k_trace_p": round(cnt["kernel_ms_shadow"], 2), "k_extend": round(cnt["kernel_ms_closest"], 2),
+                                   "k_light": round(cnt["kernel_ms_light"], 2), "shade+generate+resolve": round(cnt["kernel_ms_shade"], 2)},
             "k_extend_bytes_per_ray": round(bytes_per_closest_ray, 1),
             "k_extend_GBps": round(bytes_per_closest_ray * cnt["rays_closest"] / max(cnt["kernel_ms_closest"], 1e-9) / 1e6, 2),
             "note": "working set (%.0f MB) is resident in L2 / Infinity Cache: a low HBM fraction is expected (SURVEY.md §8d)" % (scene.info.device_bytes / 1e6),
@@ -183,7 +187,7 @@ def main():
         "rays_per_step": int(rays_per_step), "rays_closest_per_step": int(rays_closest), "rays_shadow_per_step": int(rays_shadow),
         "rays_per_sample": round(rays_per_step / max(samples, 1), 2),
         "kernel_ms_last_step": {"trace_shadow": round(cnt["kernel_ms_shadow"], 2), "trace_closest": round(cnt["kernel_ms_closest"], 2),
-                                "shade_generate_resolve": round(cnt["kernel_ms_shade"], 2)},
+                                "light_sampling": round(cnt["kernel_ms_light"], 2), "shade_generate_resolve": round(cnt["kernel_ms_shade"], 2)},
         "roofline": roofline, "cpu_baseline": cpu,
     }
     print(json.dumps(out), flush=True)

@@ -58,6 +58,10 @@ typedef struct rt_scene_info {
     uint32_t n_inner_nodes;   /* device BVH: inner nodes only, 64 B each; leaves are child references */
     uint32_t bvh_depth;       /* inner levels on the longest root-to-leaf chain */
     uint64_t device_bytes;    /* flattened scene bytes resident in HBM */
+    uint32_t n_wide_nodes;    /* occlusion BVH for is_occluded rays: 8-wide nodes, 80 B each (0 = not built, binary tree is used) */
+    uint32_t n_wide_prims;    /* its primitive records (non-emissive objects), 48 B each */
+    uint32_t wide_depth;
+    uint32_t reserved;
 } rt_scene_info;
 
 /* Work counters of the last render / cast on this scene.  A ray is one
@@ -72,6 +76,8 @@ typedef struct rt_counters {
     uint64_t closest_hits_tri, closest_hits_sph; /* shaded vertices by primitive type */
     double   kernel_ms_closest, kernel_ms_shadow, kernel_ms_shade;  /* HIP-event time per kernel class (timing enabled) */
     uint64_t launches_closest, launches_shadow;
+    uint64_t shadow_wide;     /* 8-wide occlusion-BVH nodes (80 B) fetched by is_occluded rays ("stats" on) */
+    double   kernel_ms_light; /* HIP-event time of the light-sampling kernel (Object::sample_l + the self test), timing enabled */
 } rt_counters;
 
 typedef struct rt_scene rt_scene;
@@ -95,6 +101,11 @@ int rt_scene_lights(const rt_scene* scene, uint32_t* out, uint32_t capacity);
  * {l_min[3], l_max[3], r_min[3], r_max[3], left, right, 0, 0}; child bit 31 set = leaf(object index).
  * rank[object] = position of the object's leaf in the reference's DFS (right child first). */
 int rt_scene_bvh(const rt_scene* scene, uint32_t* node_words, uint32_t* rank);
+/* Host copy of the occlusion BVH that is_occluded rays traverse (no reference counterpart: the same
+ * tree collapsed to 8 children per node with 8-bit quantised child boxes, non-emissive objects only;
+ * candidates are re-tested exactly, so results equal Scene::is_occluded, src/scene/mod.rs:452-491).
+ * node_words: 20 words per node; prim_records: 12 floats per record (sizes from rt_scene_info). */
+int rt_scene_wide_bvh(const rt_scene* scene, uint32_t* node_words, float* prim_records);
 
 /* do_render / debug_render (src/raytracer.rs:167, 353) for the pixels of one shard.
  * rgba: width*height*4 bytes, row-major, top row first, alpha 255 (SharedPixelBuffer,
@@ -117,7 +128,7 @@ int rt_occluded_rays(rt_scene* scene, const float* origins, const float* directi
 
 int rt_get_counters(const rt_scene* scene, rt_counters* out);
 /* Options: "stats" (0/1 traversal counters), "timing" (0/1 HIP-event kernel timing),
- * "max_paths" (paths in flight per pass). */
+ * "max_paths" (paths in flight per pass), "wide" (0/1: is_occluded rays use the 8-wide occlusion BVH, default 1). */
 int rt_set_option(rt_scene* scene, const char* name, uint64_t value);
 
 /* Screen tiles (no reference counterpart): pack the owned tiles of a frame into a

@@ -45,7 +45,8 @@ class RenderParams(C.Structure):
 
 class SceneInfo(C.Structure):
     _fields_ = [("n_tri", C.c_uint32), ("n_sph", C.c_uint32), ("n_mat", C.c_uint32), ("n_lights", C.c_uint32),
-                ("n_inner_nodes", C.c_uint32), ("bvh_depth", C.c_uint32), ("device_bytes", C.c_uint64)]
+                ("n_inner_nodes", C.c_uint32), ("bvh_depth", C.c_uint32), ("device_bytes", C.c_uint64),
+                ("n_wide_nodes", C.c_uint32), ("n_wide_prims", C.c_uint32), ("wide_depth", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class Counters(C.Structure):
@@ -54,7 +55,7 @@ class Counters(C.Structure):
                 ("shadow_inner", C.c_uint64), ("shadow_tris", C.c_uint64), ("shadow_sphs", C.c_uint64),
                 ("closest_hits_tri", C.c_uint64), ("closest_hits_sph", C.c_uint64),
                 ("kernel_ms_closest", C.c_double), ("kernel_ms_shadow", C.c_double), ("kernel_ms_shade", C.c_double),
-                ("launches_closest", C.c_uint64), ("launches_shadow", C.c_uint64)]
+                ("launches_closest", C.c_uint64), ("launches_shadow", C.c_uint64), ("shadow_wide", C.c_uint64), ("kernel_ms_light", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -62,7 +63,7 @@ class Counters(C.Structure):
 
 # every symbol include/rustracer_hip.h declares
 EXPORTS = [
-    "rt_last_error", "rt_init", "rt_scene_create", "rt_scene_destroy", "rt_scene_info_get", "rt_scene_lights", "rt_scene_bvh",
+    "rt_last_error", "rt_init", "rt_scene_create", "rt_scene_destroy", "rt_scene_info_get", "rt_scene_lights", "rt_scene_bvh", "rt_scene_wide_bvh",
     "rt_render", "rt_render_device", "rt_cast_primary", "rt_cast_primary_device", "rt_intersect_rays", "rt_occluded_rays",
     "rt_get_counters", "rt_set_option", "rt_tiles_per_shard", "rt_tiles_pack", "rt_tiles_unpack", "rt_screen_params",
     "rt_scene_new_named", "rt_scene_new_dragon_mesh", "rt_scene_export", "rt_make_dragon_standin", "rt_debug_math", "rt_debug_rng",
@@ -95,6 +96,7 @@ def lib():
     L.rt_scene_info_get.argtypes = [vp, C.POINTER(SceneInfo)]
     L.rt_scene_lights.argtypes = [vp, vp, u32]
     L.rt_scene_bvh.argtypes = [vp, vp, vp]
+    L.rt_scene_wide_bvh.argtypes = [vp, vp, vp]
     L.rt_render.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp]
     L.rt_render_device.argtypes = [vp, C.POINTER(RenderParams), vp, vp]
     L.rt_cast_primary.argtypes = [vp, C.POINTER(RenderParams), vp, vp]

@@ -6,6 +6,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <math.h>
+
 #include <limits>
 
 #include "rt_math.h"
@@ -444,5 +446,201 @@ class Builder {
 }  // namespace
 
 void build_bvh(const HostScene& sc, FlatBVH* out) { Builder b(sc, out); }
+
+// ---------------------------------------------------------------------------------------------
+// Occlusion BVH (layout: host_scene.h).  No reference counterpart: the reference walks its binary
+// tree for shadow rays too.  What makes this a drop-in is that is_occluded's result does not depend
+// on the order or the shape of the search: it is "some non-emissive object whose own box the ray
+// passes reports 0 < d < max_dist" (a leaf is reached iff the ray passes every ancestor box, each of
+// which contains the leaf's own box, and the slab test is monotone in the box bounds).
+namespace {
+
+struct WChild {
+    uint32_t ref;   // binary-tree child word
+    Box box;
+};
+
+class WideBuilder {
+  public:
+    WideBuilder(const HostScene& sc, const FlatBVH& bvh, WideBVH* out) : sc_(sc), bvh_(bvh), out_(out) {
+        out_->nodes.clear(); out_->prims.clear(); out_->depth = 0; out_->ok = false;
+        const uint32_t T = sc.n_tri(), S = sc.n_sph(), n = T + S;
+        if (!n) return;
+        blocker_.resize(n);
+        for (uint32_t i = 0; i < T; ++i) blocker_[i] = scene_is_black(sc.mats[sc.tri_mat[i]].emittance);
+        for (uint32_t i = 0; i < S; ++i) blocker_[T + i] = scene_is_black(sc.mats[sc.sph_mat[i]].emittance);
+        // inner nodes are numbered in pre-order: children have larger indices than their parent
+        const uint32_t ni = bvh.n_inner();
+        has_blocker_.assign(ni, 0);
+        for (uint32_t i = ni; i-- > 0;) {
+            const uint32_t* w = &bvh.words[16 * (size_t)i];
+            has_blocker_[i] = (ref_has_blocker(w[12]) || ref_has_blocker(w[13])) ? 1 : 0;
+        }
+        if (!ref_has_blocker(bvh.root)) return;
+        for (size_t i = 0; i < sc.tri_pos.size(); ++i)
+            if (!(fabsf(sc.tri_pos[i]) <= WIDE_COORD_MAX)) return;
+        for (size_t i = 0; i < sc.sph.size(); ++i)
+            if (!(fabsf(sc.sph[i]) <= WIDE_COORD_MAX / 2.0f)) return;
+
+        // breadth-first: the inner children of a node get consecutive node indices, its primitives consecutive records
+        struct Item { uint32_t ref; uint32_t level; };
+        std::vector<Item> queue;
+        queue.push_back(Item{bvh.root, 1});
+        out_->nodes.resize(20, 0u);
+        size_t head = 0;
+        bool ok = true;
+        while (head < queue.size() && ok) {
+            const Item it = queue[head];
+            const uint32_t me = (uint32_t)head;
+            ++head;
+            if (it.level > out_->depth) out_->depth = it.level;
+            std::vector<WChild> ch;
+            gather_children(it.ref, &ch);
+            // inner children first
+            std::vector<WChild> inner, prim;
+            for (size_t k = 0; k < ch.size(); ++k) ((ch[k].ref & LEAF_BIT) ? prim : inner).push_back(ch[k]);
+            const uint32_t child_base = (uint32_t)queue.size();
+            const uint32_t prim_base = out_->n_prims();
+            for (size_t k = 0; k < inner.size(); ++k) queue.push_back(Item{inner[k].ref, it.level + 1});
+            out_->nodes.resize(20 * queue.size(), 0u);
+            for (size_t k = 0; k < prim.size(); ++k) emit_prim(prim[k].ref & OBJECT_MASK);
+            std::vector<WChild> all(inner);
+            all.insert(all.end(), prim.begin(), prim.end());
+            ok = write_node(me, all, (uint32_t)inner.size(), child_base, prim_base);
+        }
+        if (!ok || queue.size() >= (1u << 23) || out_->n_prims() + 8 >= (1u << 23)) {
+            out_->nodes.clear(); out_->prims.clear(); out_->depth = 0;
+            return;
+        }
+        out_->ok = true;
+    }
+
+  private:
+    bool ref_has_blocker(uint32_t ref) const { return (ref & LEAF_BIT) ? blocker_[ref & OBJECT_MASK] != 0 : has_blocker_[ref] != 0; }
+
+    Box object_box(uint32_t obj) const {   // Bounded for Triangle / Sphere, objects.rs:293-316 (the same floats as Builder)
+        Box b;
+        const uint32_t T = sc_.n_tri();
+        if (obj < T) {
+            const float* p = &sc_.tri_pos[9 * (size_t)obj];
+            for (int k = 0; k < 3; ++k) { b.mn[k] = lo(lo(p[k], p[3 + k]), p[6 + k]); b.mx[k] = hi(hi(p[k], p[3 + k]), p[6 + k]); }
+        } else {
+            const float* c = &sc_.sph[4 * (size_t)(obj - T)];
+            for (int k = 0; k < 3; ++k) { b.mn[k] = c[k] - c[3]; b.mx[k] = c[k] + c[3]; }
+        }
+        return b;
+    }
+
+    void children_of(uint32_t inner_ref, std::vector<WChild>* out) const {
+        const uint32_t* w = &bvh_.words[16 * (size_t)inner_ref];
+        for (int c = 0; c < 2; ++c) {
+            const uint32_t ref = w[12 + c];
+            if (!ref_has_blocker(ref)) continue;
+            WChild ch;
+            ch.ref = ref;
+            memcpy(ch.box.mn, w + 6 * c, 12);
+            memcpy(ch.box.mx, w + 6 * c + 3, 12);
+            out->push_back(ch);
+        }
+    }
+
+    // Up to 8 children: open the inner child with the largest box until nothing is left to open.
+    void gather_children(uint32_t ref, std::vector<WChild>* ch) const {
+        if (ref & LEAF_BIT) {   // one-object scene
+            WChild c;
+            c.ref = ref;
+            c.box = object_box(ref & OBJECT_MASK);
+            ch->push_back(c);
+            return;
+        }
+        children_of(ref, ch);
+        for (;;) {
+            int best = -1;
+            float best_area = -1.0f;
+            for (size_t k = 0; k < ch->size(); ++k) {
+                if ((*ch)[k].ref & LEAF_BIT) continue;
+                const float a = area((*ch)[k].box);
+                if (best < 0 || a > best_area) { best = (int)k; best_area = a; }
+            }
+            if (best < 0) break;
+            std::vector<WChild> sub;
+            children_of((*ch)[best].ref, &sub);
+            if (ch->size() - 1 + sub.size() > 8) break;
+            ch->erase(ch->begin() + best);
+            ch->insert(ch->end(), sub.begin(), sub.end());
+        }
+    }
+
+    void emit_prim(uint32_t obj) {
+        const uint32_t T = sc_.n_tri();
+        float r[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (obj < T) {
+            const float* p = &sc_.tri_pos[9 * (size_t)obj];
+            r[0] = p[0]; r[1] = p[1]; r[2] = p[2]; r[3] = bits_to_float(0u);
+            r[4] = p[3]; r[5] = p[4]; r[6] = p[5]; r[7] = bits_to_float(obj);
+            r[8] = p[6]; r[9] = p[7]; r[10] = p[8];
+        } else {
+            const float* c = &sc_.sph[4 * (size_t)(obj - T)];
+            r[0] = c[0]; r[1] = c[1]; r[2] = c[2]; r[3] = bits_to_float(1u);
+            r[4] = c[3]; r[5] = bits_to_float(obj);
+        }
+        out_->prims.insert(out_->prims.end(), r, r + 12);
+    }
+
+    bool write_node(uint32_t me, const std::vector<WChild>& ch, uint32_t n_inner, uint32_t child_base, uint32_t prim_base) {
+        Box nb = empty_box();
+        for (size_t k = 0; k < ch.size(); ++k) join_into(&nb, ch[k].box);
+        uint32_t* w = &out_->nodes[20 * (size_t)me];
+        uint8_t* q = reinterpret_cast<uint8_t*>(w + 8);
+        memset(q, 0, 48);
+        uint32_t meta = 0;
+        for (int a = 0; a < 3; ++a) {
+            typedef long double real;   // 64-bit mantissa: p + q * step below is exact for every scene the range checks admit
+            const real p = (real)nb.mn[a];
+            const real ext = (real)nb.mx[a] - p;
+            if (!(ext >= 0.0L) || !(ext < 1e300L)) return false;
+            int e = WIDE_EXP_MIN;
+            if (ext > 0.0L) {
+                int ex;
+                frexpl(ext / 253.0L, &ex);   // ext / 253 < 2^ex: at most 253 steps, leaving room for the safety step below
+                e = ex;
+            }
+            if (e < WIDE_EXP_MIN) e = WIDE_EXP_MIN;
+            if (e > WIDE_EXP_MAX) return false;
+            const real step = ldexpl(1.0L, e);
+            for (size_t k = 0; k < ch.size(); ++k) {
+                // grid plane <= exact minimum and >= exact maximum in real arithmetic, with a millionth of a step to spare
+                const real mn = (real)ch[k].box.mn[a], mx = (real)ch[k].box.mx[a];
+                real ql = floorl((mn - p) / step);
+                while (ql > 0.0L && p + ql * step > mn) ql -= 1.0L;
+                if (ql > 0.0L && (mn - (p + ql * step)) < step * 1e-6L) ql -= 1.0L;
+                real qh = ceill((mx - p) / step);
+                while (p + qh * step < mx) qh += 1.0L;
+                if (((p + qh * step) - mx) < step * 1e-6L) qh += 1.0L;
+                if (ql < 0.0L) ql = 0.0L;
+                if (qh > 255.0L || !(p + ql * step <= mn) || !(p + qh * step >= mx)) return false;
+                q[8 * a + k] = (uint8_t)ql;
+                q[24 + 8 * a + k] = (uint8_t)qh;
+            }
+            for (size_t k = ch.size(); k < 8; ++k) { q[8 * a + k] = 255; q[24 + 8 * a + k] = 0; }
+            meta |= (uint32_t)(e + WIDE_EXP_BIAS) << (8 * a);
+        }
+        meta |= n_inner << 24;
+        meta |= (uint32_t)ch.size() << 28;
+        memcpy(w, nb.mn, 12);
+        w[3] = meta;
+        w[4] = child_base; w[5] = prim_base; w[6] = 0; w[7] = 0;
+        return true;
+    }
+
+    const HostScene& sc_;
+    const FlatBVH& bvh_;
+    WideBVH* out_;
+    std::vector<uint8_t> blocker_, has_blocker_;
+};
+
+}  // namespace
+
+void build_wide_bvh(const HostScene& sc, const FlatBVH& bvh, WideBVH* out) { WideBuilder b(sc, bvh, out); }
 
 }  // namespace rt

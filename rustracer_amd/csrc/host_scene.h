@@ -36,8 +36,31 @@ struct FlatBVH {
     uint32_t n_inner() const { return (uint32_t)(words.size() / 16); }
 };
 
+// Occlusion BVH for Scene::is_occluded rays (src/scene/mod.rs:452-491): the binary tree above collapsed
+// to 8 children per node, non-emissive objects only (emissive ones never block, mod.rs:481), child
+// boxes quantised to 8 bits per plane on a per-node grid (origin p, per-axis power-of-two step).
+// A quantised box always contains the exact one, so the wide traversal only selects candidates; every
+// candidate then takes the exact leaf-box test and the exact primitive test of the reference.
+// Node, 20 words (80 B):
+//   w0-2  p (grid origin = node box minimum)        w3  ex | ey<<8 | ez<<16 (step = 2^(e-128)) | n_inner<<24 | n_child<<28
+//   w4    index of the first inner child (inner children are contiguous, slots 0..n_inner-1)
+//   w5    index of the first primitive record (primitive children are contiguous, slots n_inner..n_child-1)
+//   w8-19 lo_x[8] lo_y[8] lo_z[8] hi_x[8] hi_y[8] hi_z[8], one byte per child slot
+// Primitive record, 12 floats (48 B): triangle (p1, 0) (p2, object) (p3, 0); sphere (centre, 1) (radius, object, 0, 0) (0).
+struct WideBVH {
+    std::vector<uint32_t> nodes;
+    std::vector<float> prims;
+    uint32_t depth = 0;     // nodes on the longest root-to-primitive chain
+    bool ok = false;        // false: no blockers, or the scene is outside the quantiser's range -> binary traversal only
+    uint32_t n_nodes() const { return (uint32_t)(nodes.size() / 20); }
+    uint32_t n_prims() const { return (uint32_t)(prims.size() / 12); }
+};
+const int WIDE_EXP_BIAS = 128, WIDE_EXP_MIN = -64, WIDE_EXP_MAX = 60;
+const float WIDE_COORD_MAX = 1.152921504606846976e18f;   // 2^60: larger scene or ray-origin coordinates take the binary traversal
+
 bool scene_is_black(const float* rgb);   // Spectrum::is_black, src/common.rs:40-43
 void build_bvh(const HostScene& sc, FlatBVH* out);
+void build_wide_bvh(const HostScene& sc, const FlatBVH& bvh, WideBVH* out);
 bool make_named_scene(const char* name, const char* obj_path, const float* vpos, const float* vnrm, uint32_t n_vert,
                       const uint32_t* faces, uint32_t n_face, HostScene* out, std::string* err);
 void make_dragon_standin(uint32_t nu, uint32_t nv, float* vpos, float* vnrm, uint32_t* faces);

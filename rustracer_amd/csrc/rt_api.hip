@@ -49,7 +49,7 @@ struct DevBuf {
 
 struct EventPair {
     hipEvent_t a, b;
-    int cls;   // 0 closest, 1 shadow, 2 shade/other
+    int cls;   // 0 closest, 1 shadow, 2 shade/other, 3 light sampling (k_light)
 };
 
 }  // namespace
@@ -57,11 +57,12 @@ struct EventPair {
 struct rt_scene {
     HostScene host;
     FlatBVH bvh;
+    WideBVH wide;
     std::vector<uint32_t> lights;
     bool has_triangle_light = false;
     bool uploaded = false;
 
-    DevBuf<float4> d_nodes, d_tris, d_tri_nrm, d_sph, d_mats;
+    DevBuf<float4> d_nodes, d_tris, d_tri_nrm, d_sph, d_mats, d_wnodes, d_wprims;
     DevBuf<uint2> d_sph_aux;
     DevBuf<uint32_t> d_lights, d_ovf;
     DevScene dev;
@@ -71,6 +72,8 @@ struct rt_scene {
     DevBuf<uint32_t> w_counts, w_hit_id;
     DevBuf<float> w_hit_t;
     DevBuf<float4> w_ray_o[2], w_ray_d[2], w_vP, w_vN, w_contrib, w_direct, w_stackA, w_stackB, w_radiance, w_accum;
+    DevBuf<float2> w_svis;
+    DevBuf<float4> w_lray;
     DevBuf<uint64_t> w_rng;
     DevBuf<ulonglong2> w_jump;
     uint32_t jump_nlL = 0xFFFFFFFFu;
@@ -82,13 +85,13 @@ struct rt_scene {
 
     bool opt_stats = false, opt_timing = false;
     uint64_t opt_max_paths = 1ull << 22;
-    uint32_t opt_inner_min = 12, opt_self_test = 1;
+    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 24, opt_phase_bias = 4, opt_shadow_waves = 8;
     uint32_t grid_max = 2048;
 
     std::vector<EventPair> events;
     size_t events_used = 0;
     uint64_t samples = 0;
-    uint64_t launches[3] = {0, 0, 0};
+    uint64_t launches[4] = {0, 0, 0, 0};
 };
 
 namespace {
@@ -105,13 +108,15 @@ void prepare_host(rt_scene* s) {
     const HostScene& h = s->host;
     const uint32_t T = h.n_tri(), S = h.n_sph();
     build_bvh(h, &s->bvh);
+    build_wide_bvh(h, s->bvh, &s->wide);
     s->lights.clear();
     s->has_triangle_light = false;
     for (uint32_t i = 0; i < T; ++i)
         if (!scene_is_black(h.mats[h.tri_mat[i]].emittance)) { s->lights.push_back(i); s->has_triangle_light = true; }
     for (uint32_t i = 0; i < S; ++i)
         if (!scene_is_black(h.mats[h.sph_mat[i]].emittance)) s->lights.push_back(T + i);
-    s->device_bytes = (uint64_t)s->bvh.n_inner() * 64 + (uint64_t)T * 96 + (uint64_t)S * 24 + (uint64_t)h.mats.size() * 32 + s->lights.size() * 4;
+    s->device_bytes = (uint64_t)s->bvh.n_inner() * 64 + (uint64_t)T * 96 + (uint64_t)S * 24 + (uint64_t)h.mats.size() * 32 + s->lights.size() * 4 +
+                      (uint64_t)s->wide.n_nodes() * 80 + (uint64_t)s->wide.n_prims() * 48;
 }
 
 // Device half: flatten to the kernel layout and upload, on first use.
@@ -128,7 +133,9 @@ int upload_scene(rt_scene* s) {
     s->grid_max = (uint32_t)prop.multiProcessorCount * 8u;
     if (s->grid_max == 0) s->grid_max = 2048;
 
-    const uint32_t ovf_rows = b.depth > RT_STACK_LDS ? b.depth - RT_STACK_LDS : 0;
+    // deepest traversal stack: one entry per level of the binary tree, two per level of the 8-wide occlusion tree
+    const uint32_t stack_need = b.depth > 2 * s->wide.depth ? b.depth : 2 * s->wide.depth;
+    const uint32_t ovf_rows = stack_need > RT_STACK_LDS ? stack_need - RT_STACK_LDS : 0;
     if (ovf_rows > 224) return fail(RT_ERR_LIMIT, "BVH deeper than 256 levels");
 
     std::vector<float4> tris(3 * (size_t)T), nrm(3 * (size_t)T), sph(S ? S : 1), mats(2 * (size_t)(M ? M : 1));
@@ -166,6 +173,12 @@ int upload_scene(rt_scene* s) {
     if ((rc = s->d_sph_aux.ensure(aux.size()))) return rc;
     if ((rc = s->d_mats.ensure(mats.size()))) return rc;
     if ((rc = s->d_lights.ensure(s->lights.size() ? s->lights.size() : 1))) return rc;
+    if (s->wide.ok) {
+        if ((rc = s->d_wnodes.ensure(5 * (size_t)s->wide.n_nodes()))) return rc;
+        if ((rc = s->d_wprims.ensure(3 * (size_t)s->wide.n_prims()))) return rc;
+        HIP_TRY(hipMemcpy(s->d_wnodes.p, s->wide.nodes.data(), s->wide.nodes.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(s->d_wprims.p, s->wide.prims.data(), s->wide.prims.size() * 4, hipMemcpyHostToDevice));
+    }
     if (ovf_rows && (rc = s->d_ovf.ensure((size_t)ovf_rows * s->grid_max * RT_BLOCK))) return rc;
     if (n_inner) {
         // device copy of the nodes: leaves of emissive objects carry NONBLOCK_BIT
@@ -199,6 +212,9 @@ int upload_scene(rt_scene* s) {
     }
     d.ovf = s->d_ovf.p; d.ovf_stride = s->grid_max * RT_BLOCK;
     d.inner_min = s->opt_inner_min; d.self_test = s->opt_self_test;
+    d.wnodes = s->d_wnodes.p; d.wprims = s->d_wprims.p;
+    d.n_wnodes = (s->wide.ok && s->opt_wide) ? s->wide.n_nodes() : 0u;
+    d.refill_min = s->opt_refill_min; d.phase_bias = s->opt_phase_bias;
     if ((rc = s->w_stats.ensure(ST_COUNT))) return rc;
     HIP_TRY(hipMemset(s->w_stats.p, 0, ST_COUNT * sizeof(unsigned long long)));
     s->uploaded = true;
@@ -251,7 +267,7 @@ void reset_counters(rt_scene* s, hipStream_t stream) {
     (void)hipMemsetAsync(s->w_stats.p, 0, ST_COUNT * sizeof(unsigned long long), stream);
     s->events_used = 0;
     s->samples = 0;
-    s->launches[0] = s->launches[1] = s->launches[2] = 0;
+    s->launches[0] = s->launches[1] = s->launches[2] = s->launches[3] = 0;
 }
 
 int ensure_jump(rt_scene* s, uint32_t nlL, hipStream_t stream) {
@@ -335,8 +351,12 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
     if ((rc = s->w_vP.ensure(cap_paths))) return rc;
     if ((rc = s->w_vN.ensure(cap_paths))) return rc;
     if ((rc = s->w_rng.ensure(cap_paths))) return rc;
-    const bool in_wave = nlL > 0 && nlL <= 64 && (64 % nlL) == 0;
-    if (!in_wave && (rc = s->w_contrib.ensure(cap_paths * (nlL ? nlL : 1)))) return rc;
+    const bool persist = !hemi && nlL > 0 && s->dev.n_wnodes != 0u && s->opt_persist;   // k_shadow_p over the 8-wide occlusion BVH
+    const bool in_wave = !persist && nlL > 0 && nlL <= 64 && (64 % nlL) == 0;
+    const uint64_t cap_slots = ((cap_paths + 63) / 64) * 64 * nlL;
+    if (persist && (rc = s->w_svis.ensure(cap_slots))) return rc;
+    if (persist && (rc = s->w_lray.ensure(cap_slots))) return rc;
+    if (!persist && !in_wave && (rc = s->w_contrib.ensure(cap_paths * (nlL ? nlL : 1)))) return rc;
     if ((rc = s->w_direct.ensure(cap_paths))) return rc;
     if ((rc = s->w_stackA.ensure(cap_paths * (P.bounces ? P.bounces : 1)))) return rc;
     if ((rc = s->w_stackB.ensure(cap_paths * (P.bounces ? P.bounces : 1)))) return rc;
@@ -354,6 +374,7 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
     for (int q = 0; q < 2; ++q) { pc.ray_o[q] = s->w_ray_o[q].p; pc.ray_d[q] = s->w_ray_d[q].p; }
     pc.hit_id = s->w_hit_id.p; pc.hit_t = s->w_hit_t.p;
     pc.vP = s->w_vP.p; pc.vN = s->w_vN.p; pc.rng = s->w_rng.p; pc.contrib = s->w_contrib.p; pc.direct = s->w_direct.p; pc.in_wave = in_wave ? 1u : 0u;
+    pc.svis = s->w_svis.p; pc.lray = s->w_lray.p; pc.persist = persist ? 1u : 0u;
     pc.stackA = s->w_stackA.p; pc.stackB = s->w_stackB.p; pc.radiance = s->w_radiance.p; pc.accum = s->w_accum.p;
     pc.jump = s->w_jump.p; pc.stats = s->w_stats.p; pc.rgba = rgba_dev;
 
@@ -388,8 +409,17 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
                 if (level == P.bounces) break;
                 if (nlL) {
                     const uint32_t gs = grid_for(s, (uint64_t)pc.npaths * nlL);
-                    begin_timing(s, stream, hemi ? 0 : 1, &ev);
-                    if (hemi) {
+                    begin_timing(s, stream, hemi ? 0 : (persist ? 3 : 1), &ev);
+                    if (persist) {
+                        if (s->opt_stats) hipLaunchKernelGGL(k_light<true>, dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                        else hipLaunchKernelGGL(k_light<false>, dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                        end_timing(s, stream, ev);
+                        begin_timing(s, stream, 1, &ev);
+                        if (s->opt_stats) hipLaunchKernelGGL((k_trace_p<true, 8>), dim3(gs), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                        else if (s->opt_shadow_waves >= 8) hipLaunchKernelGGL((k_trace_p<false, 8>), dim3(gs), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                        else if (s->opt_shadow_waves >= 6) hipLaunchKernelGGL((k_trace_p<false, 6>), dim3(gs), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                        else hipLaunchKernelGGL((k_trace_p<false, 5>), dim3(gs), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                    } else if (hemi) {
                         if (s->opt_stats) hipLaunchKernelGGL((k_shadow<true, true>), dim3(gs), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
                         else hipLaunchKernelGGL((k_shadow<false, true>), dim3(gs), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
                     } else {
@@ -507,11 +537,11 @@ void rt_scene_destroy(rt_scene* s) {
     if (!s) return;
     if (s->uploaded) (void)hipDeviceSynchronize();
     s->d_nodes.release(); s->d_tris.release(); s->d_tri_nrm.release(); s->d_sph.release(); s->d_mats.release();
-    s->d_sph_aux.release(); s->d_lights.release(); s->d_ovf.release();
+    s->d_sph_aux.release(); s->d_lights.release(); s->d_ovf.release(); s->d_wnodes.release(); s->d_wprims.release();
     s->w_counts.release(); s->w_hit_id.release(); s->w_hit_t.release();
     for (int q = 0; q < 2; ++q) { s->w_ray_o[q].release(); s->w_ray_d[q].release(); }
     s->w_vP.release(); s->w_vN.release(); s->w_contrib.release(); s->w_direct.release(); s->w_stackA.release(); s->w_stackB.release();
-    s->w_radiance.release(); s->w_accum.release(); s->w_rng.release(); s->w_jump.release(); s->w_stats.release();
+    s->w_radiance.release(); s->w_accum.release(); s->w_svis.release(); s->w_lray.release(); s->w_rng.release(); s->w_jump.release(); s->w_stats.release();
     s->w_frame.release(); s->w_ids.release(); s->w_ts.release(); s->w_rays.release();
     for (size_t i = 0; i < s->events.size(); ++i) { (void)hipEventDestroy(s->events[i].a); (void)hipEventDestroy(s->events[i].b); }
     delete s;
@@ -522,6 +552,7 @@ int rt_scene_info_get(const rt_scene* s, rt_scene_info* out) {
     out->n_tri = s->host.n_tri(); out->n_sph = s->host.n_sph(); out->n_mat = (uint32_t)s->host.mats.size();
     out->n_lights = (uint32_t)s->lights.size();
     out->n_inner_nodes = s->bvh.n_inner(); out->bvh_depth = s->bvh.depth; out->device_bytes = s->device_bytes;
+    out->n_wide_nodes = s->wide.n_nodes(); out->n_wide_prims = s->wide.n_prims(); out->wide_depth = s->wide.depth; out->reserved = 0;
     return RT_OK;
 }
 
@@ -535,6 +566,13 @@ int rt_scene_bvh(const rt_scene* s, uint32_t* node_words, uint32_t* rank) {
     if (!s) return fail(RT_ERR_INVALID, "NULL scene");
     if (node_words && !s->bvh.words.empty()) memcpy(node_words, s->bvh.words.data(), s->bvh.words.size() * 4);
     if (rank && !s->bvh.rank.empty()) memcpy(rank, s->bvh.rank.data(), s->bvh.rank.size() * 4);
+    return RT_OK;
+}
+
+int rt_scene_wide_bvh(const rt_scene* s, uint32_t* node_words, float* prim_records) {
+    if (!s) return fail(RT_ERR_INVALID, "NULL scene");
+    if (node_words && !s->wide.nodes.empty()) memcpy(node_words, s->wide.nodes.data(), s->wide.nodes.size() * 4);
+    if (prim_records && !s->wide.prims.empty()) memcpy(prim_records, s->wide.prims.data(), s->wide.prims.size() * 4);
     return RT_OK;
 }
 
@@ -624,14 +662,14 @@ int rt_get_counters(const rt_scene* cs, rt_counters* out) {
     out->samples = s->samples;
     if (out->rays_closest == 0 && s->launches[0] && s->samples) out->rays_closest = s->samples;   // primary cast: one ray per owned pixel
     out->closest_inner = st[ST_C_INNER]; out->closest_tris = st[ST_C_TRIS]; out->closest_sphs = st[ST_C_SPHS];
-    out->shadow_inner = st[ST_S_INNER]; out->shadow_tris = st[ST_S_TRIS]; out->shadow_sphs = st[ST_S_SPHS];
+    out->shadow_inner = st[ST_S_INNER]; out->shadow_tris = st[ST_S_TRIS]; out->shadow_sphs = st[ST_S_SPHS]; out->shadow_wide = st[ST_S_WIDE];
     out->closest_hits_tri = st[ST_HITS_TRI]; out->closest_hits_sph = st[ST_HITS_SPH];
-    double ms[3] = {0, 0, 0};
+    double ms[4] = {0, 0, 0, 0};
     for (size_t i = 0; i < s->events_used; ++i) {
         float t = 0;
         if (hipEventElapsedTime(&t, s->events[i].a, s->events[i].b) == hipSuccess) ms[s->events[i].cls] += t;
     }
-    out->kernel_ms_closest = ms[0]; out->kernel_ms_shadow = ms[1]; out->kernel_ms_shade = ms[2];
+    out->kernel_ms_closest = ms[0]; out->kernel_ms_shadow = ms[1]; out->kernel_ms_shade = ms[2]; out->kernel_ms_light = ms[3];
     out->launches_closest = s->launches[0]; out->launches_shadow = s->launches[1];
     return RT_OK;
 }
@@ -643,6 +681,11 @@ int rt_set_option(rt_scene* s, const char* name, uint64_t value) {
     else if (n == "timing") s->opt_timing = value != 0;
     else if (n == "max_paths") s->opt_max_paths = value ? value : (1ull << 22);
     else if (n == "self_test") { s->opt_self_test = value ? 1 : 0; s->dev.self_test = s->opt_self_test; }
+    else if (n == "wide") { s->opt_wide = value ? 1 : 0; s->dev.n_wnodes = (s->wide.ok && s->opt_wide) ? s->wide.n_nodes() : 0u; }
+    else if (n == "persist") s->opt_persist = value ? 1 : 0;
+    else if (n == "shadow_waves") s->opt_shadow_waves = (uint32_t)value;
+    else if (n == "refill_min") { s->opt_refill_min = value > 64 ? 64 : (value < 1 ? 1 : (uint32_t)value); s->dev.refill_min = s->opt_refill_min; }
+    else if (n == "phase_bias") { s->opt_phase_bias = (uint32_t)value; s->dev.phase_bias = s->opt_phase_bias; }
     else if (n == "inner_min") { s->opt_inner_min = value > 64 ? 64 : (uint32_t)value; s->dev.inner_min = s->opt_inner_min; }
     else return fail(RT_ERR_INVALID, "unknown option '" + n + "'");
     return RT_OK;

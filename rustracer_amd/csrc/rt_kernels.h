@@ -25,6 +25,9 @@ namespace rt {
 
 #define RT_BLOCK 256
 #define RT_STACK_LDS 16          // traversal stack entries per lane staged in LDS (16 KiB per workgroup)
+#ifndef RT_SHADOW_WAVES
+#define RT_SHADOW_WAVES 8        // k_shadow: waves per SIMD the register budget is sized for
+#endif
 #define RT_MISS 0xFFFFFFFFu
 #define RT_EPS 0.0000001f        // src/common.rs:6
 #define RT_PI 3.14159265358979323846f
@@ -44,10 +47,15 @@ struct DevScene {
     uint32_t ovf_stride;
     uint32_t self_test;      // shadow rays test the object they start on first
     uint32_t inner_min;      // traverse(): leaf tests start when fewer lanes than this are still at inner nodes
+    const float4* wnodes;    // occlusion BVH (host_scene.h WideBVH): 5 x float4 per 8-wide node (80 B)
+    const float4* wprims;    // 3 x float4 per blocker primitive record (48 B), in node order
+    uint32_t n_wnodes;       // 0: shadow rays take the binary tree
+    uint32_t refill_min;     // k_shadow_p: idle lanes that trigger a refill of the wave
+    uint32_t phase_bias;     // k_shadow_p: node step when 4 * lanes_at_nodes >= phase_bias * lanes_at_primitives
 };
 
 struct TravStats {
-    uint32_t inner, tris, sphs;
+    uint32_t inner, tris, sphs, wide;
 };
 
 struct PassCtx {
@@ -68,6 +76,9 @@ struct PassCtx {
     float4* contrib;                 // per (vertex, light sample): (rgb, visible); only when !in_wave
     float4* direct;                  // per vertex: light-sample sum (in_wave)
     uint32_t in_wave;                // nlL divides 64: k_shadow sums a vertex's light samples inside the wave
+    float2* svis;                    // per light-sample slot (ls_slot), k_light: (|wi.n|, sign bit set = dead / occluded, pdf)
+    float4* lray;                    // per light-sample slot, k_light: (wi, distance to the light sample) of the rays still to trace
+    uint32_t persist;                // light samples go through k_light + k_trace_p; k_shade_b sums pc.svis
     float4* stackA;                  // [level][slot] (direct rgb, cos)
     float4* stackB;                  // [level][slot] (reflected rgb, pdf)
     float4* radiance;                // per path slot: finished sample
@@ -78,7 +89,7 @@ struct PassCtx {
 };
 
 // traversal work is counted per ray class: [ST_C_*] closest-hit rays, [ST_S_*] shadow (any-hit) rays
-enum { ST_RAYS_CLOSEST = 0, ST_RAYS_SHADOW, ST_C_INNER, ST_C_TRIS, ST_C_SPHS, ST_S_INNER, ST_S_TRIS, ST_S_SPHS, ST_HITS_TRI, ST_HITS_SPH, ST_COUNT };
+enum { ST_RAYS_CLOSEST = 0, ST_RAYS_SHADOW, ST_C_INNER, ST_C_TRIS, ST_C_SPHS, ST_S_INNER, ST_S_TRIS, ST_S_SPHS, ST_HITS_TRI, ST_HITS_SPH, ST_S_WIDE, ST_COUNT };
 
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ vec3 xyz(float4 v) { return mk(v.x, v.y, v.z); }
@@ -328,6 +339,169 @@ __device__ __forceinline__ void traverse(const DevScene& sc, bool have_ray, vec3
     else *out_occluded = occluded;
 }
 
+#define RT_W_PRIM 0x80000000u
+#define RT_W_INV_MAX 1099511627776.0f   // 2^40: rays with a larger |1/d| component take the binary traversal
+
+// Scene::is_occluded (src/scene/mod.rs:452-491) over the 8-wide occlusion BVH (host_scene.h).
+//
+// The result of is_occluded is order- and tree-independent: true iff some non-emissive object whose
+// own box the ray passes (bvh 0.3.2 slab test, exact) reports 0 < d < max_dist.  So the wide nodes
+// only have to be conservative: a child is entered whenever the exact test on any box inside it
+// could pass.  Per node and axis, with step 2^e, grid origin p and s = (1/d) * 2^e (exact):
+//   c    = ((p - o) * (1/d))                            two roundings
+//   pad  = 2^-20 * (|c| + 256 |s|)
+//   near = fma(q_near, s, c - pad),  far = fma(q_far, s, c + pad)
+// The exact test computes fl(fl(b - o) * (1/d)) for a plane b inside [p, p + 255 * 2^e]; both differ
+// from the real-number value by at most 2^-24 * (5.1 |c| + 768 |s|) together, under a third of the
+// pad, so near <= exact near and far >= exact far on every axis, and
+// "max(nears, 0) <= min(fars, limit)" holds whenever the exact slab test (max nears <= min fars,
+// min fars > 0) does.  Candidates then take the exact box test on their own box and the exact
+// primitive test, exactly what the reference evaluates at a leaf.
+// Rays with a non-finite or huge 1/d component (0 * inf = NaN cases) or far-away origins take the
+// binary tree (traverse<1>), whose slab test has the crate's NaN behaviour.
+// Stack entries: bit 31 = primitive group, bits 30..8 = first node / record index, bits 7..0 = pending slots.
+// Shadow rays start on the surface the path just hit, and about half of them are blocked by that very
+// object at t ~ 1e-6 (the reference applies no surface offset: mod.rs:58-62).  Testing it first is the
+// reference's result, not an approximation (same candidate rule: own box, then the primitive).
+template <bool STATS>
+__device__ __forceinline__ bool self_blocks(const DevScene& sc, const BoxRay& br, vec3 o, vec3 d, float max_dist, uint32_t self_obj, TravStats* ts) {
+    float t = 0.0f, tn;
+    bool ok = false;
+    if (self_obj < sc.n_tri) {
+        const float4* tp = sc.tris + 3 * (size_t)self_obj;
+        const float4 A = tp[0], B = tp[1], C = tp[2];
+        if (__float_as_uint(B.w) & RT_INFO_BLOCKER) {
+            if (STATS) ts->tris++;
+            ok = slab(br, lo3(A.x, B.x, C.x), lo3(A.y, B.y, C.y), lo3(A.z, B.z, C.z), hi3(A.x, B.x, C.x), hi3(A.y, B.y, C.y), hi3(A.z, B.z, C.z), &tn) &&
+                 hit_triangle(xyz(A), xyz(B), xyz(C), o, d, &t);
+        }
+    } else {
+        const float4 cr = sc.sph[self_obj - sc.n_tri];
+        if (sc.sph_aux[self_obj - sc.n_tri].y & RT_INFO_BLOCKER) {
+            if (STATS) ts->sphs++;
+            ok = slab(br, cr.x - cr.w, cr.y - cr.w, cr.z - cr.w, cr.x + cr.w, cr.y + cr.w, cr.z + cr.w, &tn) && hit_sphere(cr, o, d, &t);
+        }
+    }
+    return ok && t > 0.0f && t < max_dist;
+}
+
+// Rays the 8-wide tree may take: finite, moderate 1/d and origin (see occluded()).
+__device__ __forceinline__ bool wide_ray_ok(const BoxRay& br, vec3 o) {
+    return fabsf(br.ix) <= RT_W_INV_MAX && fabsf(br.iy) <= RT_W_INV_MAX && fabsf(br.iz) <= RT_W_INV_MAX &&
+           fabsf(o.x) <= WIDE_COORD_MAX && fabsf(o.y) <= WIDE_COORD_MAX && fabsf(o.z) <= WIDE_COORD_MAX;
+}
+
+// One node of the 8-wide tree for this lane: `cur` is an inner group; on return it is the next group (0 = ray finished).
+template <bool STATS>
+__device__ __forceinline__ void wide_node_step(const DevScene& sc, const BoxRay& br, float lim, uint32_t& cur, Stack& st, TravStats* ts) {
+    const uint32_t node = (cur >> 8) + (uint32_t)__ffs((int)(cur & 0xFFu)) - 1u;
+    uint32_t rest = cur & (cur - 1u);
+    if (!(rest & 0xFFu)) rest = 0u;
+    const float4* np = sc.wnodes + 5 * (size_t)node;
+    const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+    if (STATS) ts->wide++;
+    const uint32_t meta = __float_as_uint(n0.w);
+    const float sx = ldexpf(br.ix, (int)(meta & 0xFFu) - WIDE_EXP_BIAS);
+    const float sy = ldexpf(br.iy, (int)((meta >> 8) & 0xFFu) - WIDE_EXP_BIAS);
+    const float sz = ldexpf(br.iz, (int)((meta >> 16) & 0xFFu) - WIDE_EXP_BIAS);
+    const float cx = (n0.x - br.ox) * br.ix, cy = (n0.y - br.oy) * br.iy, cz = (n0.z - br.oz) * br.iz;
+    const float px = fmaf(256.0f, fabsf(sx), fabsf(cx)) * 0x1p-20f;
+    const float py = fmaf(256.0f, fabsf(sy), fabsf(cy)) * 0x1p-20f;
+    const float pz = fmaf(256.0f, fabsf(sz), fabsf(cz)) * 0x1p-20f;
+    const float cnx = cx - px, cfx = cx + px, cny = cy - py, cfy = cy + py, cnz = cz - pz, cfz = cz + pz;
+    // plane bytes of the 8 slots: near = lo when the direction component is positive
+    const uint32_t lox0 = __float_as_uint(n2.x), lox1 = __float_as_uint(n2.y), loy0 = __float_as_uint(n2.z), loy1 = __float_as_uint(n2.w);
+    const uint32_t loz0 = __float_as_uint(n3.x), loz1 = __float_as_uint(n3.y), hix0 = __float_as_uint(n3.z), hix1 = __float_as_uint(n3.w);
+    const uint32_t hiy0 = __float_as_uint(n4.x), hiy1 = __float_as_uint(n4.y), hiz0 = __float_as_uint(n4.z), hiz1 = __float_as_uint(n4.w);
+    const uint32_t nx[2] = {br.sx ? hix0 : lox0, br.sx ? hix1 : lox1}, fx[2] = {br.sx ? lox0 : hix0, br.sx ? lox1 : hix1};
+    const uint32_t ny[2] = {br.sy ? hiy0 : loy0, br.sy ? hiy1 : loy1}, fy[2] = {br.sy ? loy0 : hiy0, br.sy ? loy1 : hiy1};
+    const uint32_t nz[2] = {br.sz ? hiz0 : loz0, br.sz ? hiz1 : loz1}, fz[2] = {br.sz ? loz0 : hiz0, br.sz ? loz1 : hiz1};
+    uint32_t hm = 0u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int w = i >> 2, sh = 8 * (i & 3);
+        const float tnx = fmaf((float)((nx[w] >> sh) & 0xFFu), sx, cnx), tfx = fmaf((float)((fx[w] >> sh) & 0xFFu), sx, cfx);
+        const float tny = fmaf((float)((ny[w] >> sh) & 0xFFu), sy, cny), tfy = fmaf((float)((fy[w] >> sh) & 0xFFu), sy, cfy);
+        const float tnz = fmaf((float)((nz[w] >> sh) & 0xFFu), sz, cnz), tfz = fmaf((float)((fz[w] >> sh) & 0xFFu), sz, cfz);
+        const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
+        const float tf = fminf(fminf(tfx, tfy), fminf(tfz, lim));
+        hm |= tn <= tf ? (1u << i) : 0u;
+    }
+    hm &= (1u << (meta >> 28)) - 1u;                       // slots in use
+    const uint32_t k = (meta >> 24) & 0xFu;
+    const uint32_t ih = hm & ((1u << k) - 1u), ph = hm >> k;
+    uint32_t a = ph ? (RT_W_PRIM | (__float_as_uint(n1.y) << 8) | ph) : 0u;   // primitives first: a blocker ends the ray
+    uint32_t b = ih ? ((__float_as_uint(n1.x) << 8) | ih) : 0u;
+    uint32_t c = rest;
+    if (!a) { a = b; b = 0u; }
+    if (!a) { a = c; c = 0u; }
+    if (c) st.push(c);
+    if (b) st.push(b);
+    cur = a;
+    if (!cur && st.sp > 0) cur = st.pop();
+}
+
+// One primitive record for this lane: `cur` is a primitive group.  Returns true when it blocks the ray
+// (cur = 0); otherwise cur is the next group (0 = ray finished unblocked).
+template <bool STATS>
+__device__ __forceinline__ bool wide_prim_step(const DevScene& sc, const BoxRay& br, vec3 o, vec3 d, float max_dist, uint32_t& cur, Stack& st, TravStats* ts) {
+    const uint32_t prim = ((cur >> 8) & 0x7FFFFFu) + (uint32_t)__ffs((int)(cur & 0xFFu)) - 1u;
+    uint32_t rest = cur & (cur - 1u);
+    if (!(rest & 0xFFu)) rest = 0u;
+    const float4* tp = sc.wprims + 3 * (size_t)prim;
+    const float4 A = tp[0], B = tp[1];
+    float t = 0.0f, tn;
+    bool ok;
+    if (__float_as_uint(A.w) == 0u) {
+        const float4 C = tp[2];
+        if (STATS) ts->tris++;
+        ok = slab(br, lo3(A.x, B.x, C.x), lo3(A.y, B.y, C.y), lo3(A.z, B.z, C.z), hi3(A.x, B.x, C.x), hi3(A.y, B.y, C.y), hi3(A.z, B.z, C.z), &tn) &&
+             hit_triangle(xyz(A), xyz(B), xyz(C), o, d, &t);
+    } else {
+        if (STATS) ts->sphs++;
+        const float r = B.x;
+        ok = slab(br, A.x - r, A.y - r, A.z - r, A.x + r, A.y + r, A.z + r, &tn) && hit_sphere(make_float4(A.x, A.y, A.z, r), o, d, &t);
+    }
+    if (ok && t > 0.0f && t < max_dist) {
+        cur = 0u;
+        return true;
+    }
+    cur = rest;
+    if (!cur && st.sp > 0) cur = st.pop();
+    return false;
+}
+
+template <bool STATS>
+__device__ __forceinline__ bool occluded(const DevScene& sc, bool have_ray, vec3 o, vec3 d, float max_dist, uint32_t self_obj, Stack& st, TravStats* ts) {
+    const BoxRay br = make_box_ray(o, d);
+    const bool wide = have_ray && sc.n_wnodes != 0u && wide_ray_ok(br, o);
+    const bool binary = have_ray && !wide;
+    bool occ = false;
+    uint32_t cur = wide ? 1u : 0u;   // inner group {node 0}
+    if (wide && self_obj != RT_MISS && self_blocks<STATS>(sc, br, o, d, max_dist, self_obj, ts)) { occ = true; cur = 0u; }
+    const float lim = prune_limit(max_dist);
+    const uint32_t inner_min = sc.inner_min;
+    st.sp = 0;
+    for (;;) {
+        for (;;) {
+            const bool at_inner = cur != 0u && !(cur & RT_W_PRIM);
+            const unsigned long long mi = __ballot(at_inner);
+            if (!mi) break;
+            if ((uint32_t)__popcll(mi) < inner_min && __ballot((cur & RT_W_PRIM) != 0u) != 0ull) break;
+            if (at_inner) wide_node_step<STATS>(sc, br, lim, cur, st, ts);
+        }
+        if (cur & RT_W_PRIM)
+            if (wide_prim_step<STATS>(sc, br, o, d, max_dist, cur, st, ts)) occ = true;
+        if (__ballot(cur != 0u) == 0ull) break;
+    }
+    if (__ballot(binary) != 0ull) {
+        bool occ2 = false;
+        traverse<1, STATS>(sc, binary, o, d, max_dist, self_obj, st, nullptr, nullptr, &occ2, ts);
+        if (binary) occ = occ2;
+    }
+    return occ;
+}
+
 __device__ __forceinline__ uint32_t object_info(const DevScene& sc, uint32_t obj) {
     return obj < sc.n_tri ? __float_as_uint(sc.tris[3 * (size_t)obj + 1].w) : sc.sph_aux[obj - sc.n_tri].y;
 }
@@ -436,17 +610,19 @@ __device__ __forceinline__ uint32_t block_sum_to_thread0(uint32_t v, uint32_t* s
 template <bool STATS>
 __device__ __forceinline__ void flush_stats(unsigned long long* stats, const TravStats& ts, int base) {
     if (!STATS) return;
-    uint32_t a = ts.inner, b = ts.tris, c = ts.sphs;
+    uint32_t a = ts.inner, b = ts.tris, c = ts.sphs, w = ts.wide;
     for (int off = 32; off > 0; off >>= 1) {
         a += __shfl_xor(a, off);
         b += __shfl_xor(b, off);
         c += __shfl_xor(c, off);
+        w += __shfl_xor(w, off);
     }
     const unsigned long long active = __ballot(1);
     if ((int)__lane_id() == __ffsll((long long)active) - 1) {
         atomicAdd(&stats[base], (unsigned long long)a);
         atomicAdd(&stats[base + 1], (unsigned long long)b);
         atomicAdd(&stats[base + 2], (unsigned long long)c);
+        if (w) atomicAdd(&stats[ST_S_WIDE], (unsigned long long)w);
     }
 }
 
@@ -465,7 +641,7 @@ template <bool STATS>
 __global__ void __launch_bounds__(RT_BLOCK) k_primary(DevScene sc, rt_render_params P, uint32_t tiles_x, uint32_t n_own_pixels,
                                                      uint32_t* ids, float* ts_out, uint8_t* rgba, unsigned long long* stats) {
     RT_STACK_DECL;
-    TravStats tst = {0, 0, 0};
+    TravStats tst = {0, 0, 0, 0};
     const vec3 cam = mk(P.cam[0], P.cam[1], P.cam[2]);
     for (uint32_t op = blockIdx.x * RT_BLOCK + threadIdx.x; op < n_own_pixels; op += gridDim.x * RT_BLOCK) {
         uint32_t x, y;
@@ -515,7 +691,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_generate(PassCtx pc) {
 template <bool STATS>
 __global__ void __launch_bounds__(RT_BLOCK, 8) k_extend(DevScene sc, PassCtx pc, uint32_t level) {
     RT_STACK_DECL;
-    TravStats tst = {0, 0, 0};
+    TravStats tst = {0, 0, 0, 0};
     const uint32_t n = pc.counts[level];
     const float4* ro = pc.ray_o[level & 1];
     const float4* rd = pc.ray_d[level & 1];
@@ -582,9 +758,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_a(DevScene sc, PassCtx pc, u
 // term (16 B per vertex) goes to HBM; otherwise each sample goes to pc.contrib for k_shade_b.
 // HEMI = the hemisphere direct-lighting estimator (not in the reference source).
 template <bool STATS, bool HEMI>
-__global__ void __launch_bounds__(RT_BLOCK, 8) k_shadow(DevScene sc, PassCtx pc, uint32_t level) {
+__global__ void __launch_bounds__(RT_BLOCK, RT_SHADOW_WAVES) k_shadow(DevScene sc, PassCtx pc, uint32_t level) {
     RT_STACK_DECL;
-    TravStats tst = {0, 0, 0};
+    TravStats tst = {0, 0, 0, 0};
     const uint32_t n = pc.counts[level] * pc.nlL;
     const float4* ro = pc.ray_o[level & 1];
     const uint32_t L = pc.P.light_samples;
@@ -625,9 +801,8 @@ __global__ void __launch_bounds__(RT_BLOCK, 8) k_shadow(DevScene sc, PassCtx pc,
             }
         }
         if (!HEMI) {
-            bool occluded = false;
-            traverse<1, STATS>(sc, alive, p, wi, d_s, sc.self_test ? __float_as_uint(N4.w) - 1u : RT_MISS, st, nullptr, nullptr, &occluded, &tst);
-            if (alive && !occluded) out = make_float4(c.x, c.y, c.z, 1.0f);
+            const bool blocked = occluded<STATS>(sc, alive, p, wi, d_s, sc.self_test ? __float_as_uint(N4.w) - 1u : RT_MISS, st, &tst);
+            if (alive && !blocked) out = make_float4(c.x, c.y, c.z, 1.0f);
         } else {
             uint32_t id = RT_MISS;
             float t;
@@ -668,6 +843,187 @@ __global__ void __launch_bounds__(RT_BLOCK, 8) k_shadow(DevScene sc, PassCtx pc,
     flush_stats<STATS>(pc.stats, tst, HEMI ? ST_C_INNER : ST_S_INNER);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Light sampling with importance (one_bounce_radiance_importance, src/raytracer.rs:251-283) in two
+// kernels, split where the divergence class changes:
+//   k_light    one thread per path vertex, looping over its lights x light samples: Object::sample_l
+//              (objects.rs:101-116; full-rate f64 polynomial trig, every lane busy) and the test of
+//              the object the ray starts on, which ends about half of all shadow rays;
+//   k_trace_p  Scene::is_occluded for the survivors, as a persistent wave loop over the 8-wide
+//              occlusion BVH that refills finished lanes (per-ray cost varies 1..40 nodes).
+// Slot of (vertex e, light sample j): tiles of 64 vertices, sample-major inside a tile, so that
+// k_light (lane = vertex), k_trace_p (row of 64 slots) and k_shade_b (lane = vertex) all touch
+// consecutive addresses.  pc.svis[slot] = (|wi.n|, pdf), sign bit of x set when the sample does not
+// count (dead vertex or occluded); pc.lray[slot] = (wi, distance) for rays that k_trace_p must trace.
+__device__ __forceinline__ size_t ls_slot(uint32_t e, uint32_t j, uint32_t nlL) {
+    return (size_t)(e >> 6) * (64u * (size_t)nlL) + (size_t)j * 64u + (e & 63u);
+}
+__device__ __forceinline__ uint32_t ls_vertex(size_t slot, uint32_t nlL) {
+    const size_t tile = slot / (64u * (size_t)nlL);
+    return (uint32_t)(tile * 64u + (slot & 63u));
+}
+
+template <bool STATS>
+__global__ void __launch_bounds__(RT_BLOCK) k_light(DevScene sc, PassCtx pc, uint32_t level) {
+    RT_STACK_DECL;
+    TravStats tst = {0, 0, 0, 0};
+    const uint32_t n = pc.counts[level], n_round = (n + 63u) & ~63u;
+    const float4* ro = pc.ray_o[level & 1];
+    const uint32_t nlL = pc.nlL, L = pc.P.light_samples;
+    uint32_t* flags = reinterpret_cast<uint32_t*>(pc.svis);
+    for (uint32_t e = blockIdx.x * RT_BLOCK + threadIdx.x; e < n_round; e += gridDim.x * RT_BLOCK) {
+        float4 N4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (e < n) N4 = pc.vN[e];
+        if (__float_as_uint(N4.w) == 0u) {                       // path ended at this level (or padding of the last tile)
+            for (uint32_t j = 0; j < nlL; ++j) flags[2 * ls_slot(e, j, nlL)] = 0x80000000u;
+            continue;
+        }
+        const float4 P4 = pc.vP[e];
+        const vec3 p = xyz(P4), nrm = xyz(N4);
+        const uint64_t rng0 = pc.rng[__float_as_uint(ro[e].w)];
+        // the object the rays start on, fetched once per vertex (see self_blocks())
+        const uint32_t self_obj = sc.self_test ? __float_as_uint(N4.w) - 1u : RT_MISS;
+        bool self_is_tri = false, self_is_sph = false;
+        float4 A = make_float4(0, 0, 0, 0), B = A, C = A;
+        if (self_obj != RT_MISS) {
+            if (self_obj < sc.n_tri) {
+                const float4* tp = sc.tris + 3 * (size_t)self_obj;
+                A = tp[0]; B = tp[1]; C = tp[2];
+                self_is_tri = (__float_as_uint(B.w) & RT_INFO_BLOCKER) != 0u;
+            } else {
+                A = sc.sph[self_obj - sc.n_tri];
+                self_is_sph = (sc.sph_aux[self_obj - sc.n_tri].y & RT_INFO_BLOCKER) != 0u;
+            }
+        }
+        const float bmnx = lo3(A.x, B.x, C.x), bmny = lo3(A.y, B.y, C.y), bmnz = lo3(A.z, B.z, C.z);
+        const float bmxx = hi3(A.x, B.x, C.x), bmxy = hi3(A.y, B.y, C.y), bmxz = hi3(A.z, B.z, C.z);
+        for (uint32_t j = 0; j < nlL; ++j) {
+            const ulonglong2 jm = pc.jump[j];
+            uint64_t rng = jm.x * rng0 + jm.y;
+            const uint32_t light = sc.lights[j / L];
+            const float4 cr = sc.sph[light - sc.n_tri];
+            const vec3 sp = add(xyz(cr), scale(random_sphere(&rng), cr.w));      // Sphere::random_point, objects.rs:223-226
+            const vec3 ps = sub(sp, p);
+            const float d_s = length3(ps);
+            const vec3 wi = scale(ps, 1.0f / d_s);
+            const float d_c = length3(sub(xyz(cr), p));
+            const float cos_a = (d_c * d_c + cr.w * cr.w - d_s * d_s) / (2.0f * d_c * cr.w);
+            const float pdf = 2.0f * RT_PI * (1.0f - cos_a);
+            const float cos_theta = fabsf(dot3(wi, nrm));
+            bool blocked = false;
+            const BoxRay br = make_box_ray(p, wi);
+            const bool binary = !wide_ray_ok(br, p);
+            if (!binary && (self_is_tri || self_is_sph)) {
+                float t = 0.0f, tn;
+                bool ok;
+                if (self_is_tri) {
+                    if (STATS) tst.tris++;
+                    ok = slab(br, bmnx, bmny, bmnz, bmxx, bmxy, bmxz, &tn) && hit_triangle(xyz(A), xyz(B), xyz(C), p, wi, &t);
+                } else {
+                    if (STATS) tst.sphs++;
+                    ok = slab(br, A.x - A.w, A.y - A.w, A.z - A.w, A.x + A.w, A.y + A.w, A.z + A.w, &tn) && hit_sphere(A, p, wi, &t);
+                }
+                blocked = ok && t > 0.0f && t < d_s;
+            }
+            if (__ballot(binary) != 0ull) {
+                // 0 * inf = NaN cases of the slab test, or far-away coordinates: settled right here on the binary tree, which
+                // has the crate's NaN behaviour (k_trace_p skips these rays)
+                bool occ = false;
+                traverse<1, STATS>(sc, binary, p, wi, d_s, self_obj, st, nullptr, nullptr, &occ, &tst);
+                if (binary) blocked = occ;
+            }
+            const size_t sl = ls_slot(e, j, nlL);
+            pc.svis[sl] = make_float2(__uint_as_float(__float_as_uint(cos_theta) | (blocked ? 0x80000000u : 0u)), pdf);
+            if (!blocked) pc.lray[sl] = make_float4(wi.x, wi.y, wi.z, d_s);
+        }
+    }
+    flush_stats<STATS>(pc.stats, tst, ST_S_INNER);
+}
+
+// Wave state of k_trace_p: a wave owns chunks of RT_CHUNK consecutive slots (chunk = wave index, then
+// + number of waves), reads them a row of 64 at a time, and hands the live rays of a row to its idle
+// lanes as they become free (`pend` = live rays of the current row not yet handed out).
+#define RT_CHUNK 512u
+template <bool STATS, int WAVES>   // WAVES: waves per SIMD the register budget is sized for
+__global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCtx pc, uint32_t level) {
+    RT_STACK_DECL;
+    __shared__ uint32_t s_pub[RT_BLOCK];
+    uint32_t* pub = s_pub + (threadIdx.x & ~63u);
+    TravStats tst = {0, 0, 0, 0};
+    const uint32_t nlL = pc.nlL;
+    const uint32_t n_slots = ((pc.counts[level] + 63u) >> 6) * 64u * nlL;      // < 2^31 (render_impl caps paths * nlL at 2^30)
+    const uint32_t n_waves = gridDim.x * (RT_BLOCK / 64);
+    const uint32_t lane = __lane_id();
+    uint32_t chunk = __builtin_amdgcn_readfirstlane((blockIdx.x * RT_BLOCK + threadIdx.x) >> 6);
+    uint32_t next = chunk * RT_CHUNK;
+    uint32_t chunk_end = next < n_slots ? (n_slots - next < RT_CHUNK ? n_slots : next + RT_CHUNK) : next;
+    unsigned long long pend = 0ull;
+    uint32_t row_base = 0u;
+    const uint32_t refill_min = sc.refill_min, phase_bias = sc.phase_bias;
+    uint32_t* flags = reinterpret_cast<uint32_t*>(pc.svis);
+
+    // the ray this lane is tracing (cur != 0)
+    uint32_t cur = 0u, slot = 0u, cos_bits = 0u;
+    vec3 o = mk(0.0f, 0.0f, 0.0f), d = mk(0.0f, 0.0f, 1.0f);
+    BoxRay br = make_box_ray(o, d);
+    float max_dist = 0.0f, lim = 0.0f;
+
+    for (;;) {
+        const unsigned long long idle = __ballot(cur == 0u);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if ((pend != 0ull || next < n_slots) && n_idle >= refill_min) {
+            if (pend == 0ull) {                                  // next row of 64 slots: which rays are still to trace
+                const uint32_t f = flags[2 * (size_t)(next + lane)];
+                pend = __ballot(!(f & 0x80000000u));
+                row_base = next;
+                next += 64u;
+                if (next == chunk_end) {
+                    chunk += n_waves;
+                    next = chunk * RT_CHUNK;
+                    chunk_end = next < n_slots ? (n_slots - next < RT_CHUNK ? n_slots : next + RT_CHUNK) : next;
+                }
+                if (pend == 0ull) continue;
+            }
+            const uint32_t n_pend = (uint32_t)__popcll(pend);
+            const uint32_t take = n_pend < n_idle ? n_pend : n_idle;
+            const bool offered = ((pend >> lane) & 1ull) != 0ull;
+            const uint32_t prank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pend >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pend, 0u));
+            if (offered && prank < take) pub[prank] = row_base + lane;
+            pend = __ballot(offered && prank >= take);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t irank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            const bool mine = cur == 0u && irank < take;
+            if (mine) {
+                slot = pub[irank];
+                const uint32_t e = ls_vertex(slot, nlL);
+                const float4 R4 = pc.lray[slot];
+                const float4 P4 = pc.vP[e];
+                cos_bits = flags[2 * (size_t)slot];
+                o = xyz(P4); d = xyz(R4); max_dist = R4.w;
+                br = make_box_ray(o, d);
+                lim = prune_limit(max_dist);
+                if (wide_ray_ok(br, o)) {      // the others were settled by k_light on the binary tree
+                    cur = 1u;                  // inner group {node 0}
+                    st.sp = 0;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
+        if (n_idle == 64u) break;
+        const bool at_node = cur != 0u && !(cur & RT_W_PRIM);
+        const bool at_prim = (cur & RT_W_PRIM) != 0u;
+        const uint32_t n_node = (uint32_t)__popcll(__ballot(at_node)), n_prim = (uint32_t)__popcll(__ballot(at_prim));
+        if (n_node != 0u && (n_prim == 0u || 4u * n_node >= phase_bias * n_prim)) {
+            if (at_node) wide_node_step<STATS>(sc, br, lim, cur, st, &tst);
+        } else if (at_prim) {
+            if (wide_prim_step<STATS>(sc, br, o, d, max_dist, cur, st, &tst)) flags[2 * (size_t)slot] = cos_bits | 0x80000000u;
+        }
+    }
+    flush_stats<STATS>(pc.stats, tst, ST_S_INNER);
+}
+
 // The rest of one_bounce_radiance_importance and global_illumination (src/raytracer.rs:282-326).
 __global__ void __launch_bounds__(RT_BLOCK) k_shade_b(DevScene sc, PassCtx pc, uint32_t level) {
     const uint32_t n = pc.counts[level];
@@ -693,7 +1049,21 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_b(DevScene sc, PassCtx pc, u
                 const float4 m0 = sc.mats[2 * mat], m1 = sc.mats[2 * mat + 1];
                 const vec3 p = xyz(P4), nrm = xyz(N4);
                 vec3 l = mk(0.0f, 0.0f, 0.0f);
-                if (pc.in_wave) {
+                if (pc.persist) {
+                    // one_bounce_radiance_importance's sample loop (raytracer.rs:266-283) over what k_shadow_p left per ray
+                    const vec3 f = __float_as_uint(m0.x) == RT_BSDF_DIFFUSE ? scale(mk(m0.y, m0.z, m0.w), 1.0f / RT_PI) : mk(0.0f, 0.0f, 0.0f);   // Object::bsdf
+                    for (uint32_t g = 0; g < pc.n_groups; ++g) {
+                        const uint32_t light = sc.lights[g];
+                        const vec3 le = xyz(sc.mats[2 * (sc.sph_aux[light - sc.n_tri].y & ~RT_INFO_BLOCKER) + 1]);
+                        const vec3 base = mul3(le, f);
+                        vec3 color = mk(0.0f, 0.0f, 0.0f);
+                        for (uint32_t s = 0; s < L; ++s) {
+                            const float2 v = pc.svis[ls_slot(e, g * L + s, pc.nlL)];
+                            if (!(__float_as_uint(v.x) & 0x80000000u)) color = add(color, scale(scale(base, v.x), v.y));   // raytracer.rs:279
+                        }
+                        l = add(l, scale(color, inv_light_samples));                // raytracer.rs:282
+                    }
+                } else if (pc.in_wave) {
                     l = xyz(pc.direct[e]);                                          // summed by k_shadow
                 } else {
                     const float4* cp = pc.contrib + (size_t)e * pc.nlL;
@@ -769,7 +1139,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_resolve(PassCtx pc) {
 // Arbitrary rays (rt_intersect_rays / rt_occluded_rays).
 __global__ void __launch_bounds__(RT_BLOCK) k_rays_closest(DevScene sc, const float* org, const float* dir, uint32_t n, uint32_t* ids, float* ts_out) {
     RT_STACK_DECL;
-    TravStats tst = {0, 0, 0};
+    TravStats tst = {0, 0, 0, 0};
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
         uint32_t id;
         float t;
@@ -780,11 +1150,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_rays_closest(DevScene sc, const fl
 }
 __global__ void __launch_bounds__(RT_BLOCK) k_rays_occluded(DevScene sc, const float* org, const float* dir, const float* maxd, uint32_t n, uint8_t* out) {
     RT_STACK_DECL;
-    TravStats tst = {0, 0, 0};
+    TravStats tst = {0, 0, 0, 0};
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
-        bool occ = false;
-        traverse<1, false>(sc, true, mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]), mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), maxd[i], RT_MISS, st, nullptr,
-                           nullptr, &occ, &tst);
+        const bool occ = occluded<false>(sc, true, mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]), mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), maxd[i], RT_MISS, st, &tst);
         out[i] = occ ? 1 : 0;
     }
 }

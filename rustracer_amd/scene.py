@@ -156,6 +156,13 @@ class Scene:
         check(lib().rt_scene_bvh(self.handle, ptr(words), ptr(rank)))
         return words, rank
 
+    def wide_bvh(self):
+        """(node words [n_wide_nodes,20], primitive records [n_wide_prims,12]) of the 8-wide occlusion BVH."""
+        nodes = np.zeros((self.info.n_wide_nodes, 20), np.uint32)
+        prims = np.zeros((self.info.n_wide_prims, 12), np.float32)
+        check(lib().rt_scene_wide_bvh(self.handle, ptr(nodes), ptr(prims)))
+        return nodes, prims
+
     def intersect_rays(self, origins, directions):
         """Scene::intersect (src/scene/mod.rs:406) for a batch of rays -> (object ids, distances)."""
         o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)

@@ -141,6 +141,9 @@ def test_random_rays_match_oracle(scenes, name):
     d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
     d[:50, 0] = 0.0                                     # zero components: inf / NaN paths of the slab test
     d[50:100, 1] = 0.0
+    d[100:130, 2] = np.float32(1e-13)                    # |1/d| beyond 2^40: is_occluded falls back from the 8-wide tree to the binary one
+    d[130:160, 0] = np.float32(-3e-12)                   # |1/d| just inside the 8-wide tree's range
+    d[160:170, 1] = np.float32(1e-42)                    # denormal component: 1/d = inf
     gi, gt = gsc.intersect_rays(org, d)
     oi, ot = osc.intersect_rays(org, d)
     assert np.array_equal(gi, oi)
@@ -236,7 +239,14 @@ def test_stats_option_counts_and_same_image(scenes):
     assert np.array_equal(plain, inst)
     assert c1["rays_closest"] == c0["rays_closest"] and c1["rays_shadow"] == c0["rays_shadow"]
     assert c1["closest_inner"] > c1["rays_closest"] and c1["closest_tris"] > 0 and c1["closest_sphs"] > 0
-    assert c1["shadow_inner"] > c1["rays_shadow"] and c1["shadow_tris"] > 0
+    assert c1["shadow_wide"] > 0 and c1["shadow_inner"] == 0 and c1["shadow_tris"] > 0     # is_occluded rays walk the 8-wide occlusion BVH
+    gsc.set_option("wide", 0)
+    gsc.set_option("stats", 1)
+    binary, c2 = gpu_render(gsc, p)
+    gsc.set_option("stats", 0)
+    gsc.set_option("wide", 1)
+    assert np.array_equal(plain, binary)                                                     # ... and the binary tree gives the same image
+    assert c2["shadow_wide"] == 0 and c2["shadow_inner"] > c2["rays_shadow"] and c2["rays_shadow"] == c0["rays_shadow"]
     assert c0["closest_inner"] == 0 and c0["shadow_inner"] == 0
     assert c1["closest_hits_tri"] + c1["closest_hits_sph"] > 0
     # closest-hit rays: ordered traversal with pruning never does more work than the reference's
