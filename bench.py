@@ -135,7 +135,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- roofline of the dominant kernel (k_shadow: Scene::is_occluded rays) ----
+    # ---- roofline of the dominant kernel (k_trace_p: Scene::is_occluded for the light-sample rays that survive k_light) ----
     roofline = None
     if a.stats_spp > 0 and cnt["launches_shadow"] > 0:
         sp = params.copy()
@@ -145,29 +145,49 @@ def main():
         torch.cuda.synchronize(dev)
         sc = scene.counters()
         scene.set_option("stats", 0)
-        # bytes/ray = 64*inner + 48*tri + 16*sph + 48 (ray record in, result out); is_occluded rays
-        # walk the 8-wide occlusion BVH, whose nodes are 80 B
-        bytes_per_shadow_ray = (80.0 * sc["shadow_wide"] + 64.0 * sc["shadow_inner"] + 48.0 * sc["shadow_tris"] + 16.0 * sc["shadow_sphs"]) \
-            / max(sc["rays_shadow"], 1) + 48.0
+        ts = dict(zip(["node_steps", "node_lanes", "prim_steps", "prim_lanes", "refills", "refill_lanes"], sc["trace_steps"]))
+        launches = cnt["launches_shadow"]
+        avg_ms = cnt["kernel_ms_shadow"] / launches
+        if ts["refill_lanes"] > 0:
+            # Algorithmic bytes of one traced ray: 80 B per 8-wide node visited, 48 B per primitive record tested, and
+            # 56 B of ray I/O (32 B ray record + 16 B vertex position + 4 B flag read + 4 B flag write-back, the last counted for every ray).
+            # k_light settles the other is_occluded rays (test of the object the ray starts on) before this kernel; they are not counted here.
+            traced_frac = ts["refill_lanes"] / max(sc["rays_shadow"], 1)
+            nodes_per_ray = ts["node_lanes"] / ts["refill_lanes"]
+            prims_per_ray = ts["prim_lanes"] / ts["refill_lanes"]
+            bytes_per_ray = 80.0 * nodes_per_ray + 48.0 * prims_per_ray + 56.0
+            rays_per_launch = traced_frac * cnt["rays_shadow"] / launches
+            kernel = "k_trace_p<false,8> (Scene::is_occluded: persistent any-hit traversal of the 8-wide occlusion BVH with lane refill)"
+            per_ray = {"wide_nodes_80B": round(nodes_per_ray, 3), "prim_records_48B": round(prims_per_ray, 3), "ray_io_B": 56,
+                       "traced_fraction_of_is_occluded_rays": round(traced_frac, 4),
+                       "lanes_per_node_step": round(ts["node_lanes"] / max(ts["node_steps"], 1), 1),
+                       "lanes_per_prim_step": round(ts["prim_lanes"] / max(ts["prim_steps"], 1), 1),
+                       "lanes_per_refill": round(ts["refill_lanes"] / max(ts["refills"], 1), 1)}
+        else:
+            # binary-tree kernel (option wide=0 / persist=0, or a scene outside the 8-wide tree's range): SURVEY.md §8(d) formula
+            bytes_per_ray = (80.0 * sc["shadow_wide"] + 64.0 * sc["shadow_inner"] + 48.0 * sc["shadow_tris"] + 16.0 * sc["shadow_sphs"]) \
+                / max(sc["rays_shadow"], 1) + 48.0
+            rays_per_launch = cnt["rays_shadow"] / launches
+            kernel = "k_shadow<false,false> (Scene::is_occluded, one thread per light sample)"
+            per_ray = {"wide_nodes_80B": round(sc["shadow_wide"] / max(sc["rays_shadow"], 1), 3), "binary_nodes_64B": round(sc["shadow_inner"] / max(sc["rays_shadow"], 1), 3),
+                       "tri_48B": round(sc["shadow_tris"] / max(sc["rays_shadow"], 1), 3)}
+        achieved = bytes_per_ray * rays_per_launch / (avg_ms * 1e-3) / 1e9
         bytes_per_closest_ray = (64.0 * sc["closest_inner"] + 48.0 * sc["closest_tris"] + 16.0 * sc["closest_sphs"]) / max(sc["rays_closest"], 1) + 48.0 \
             + (80.0 * sc["closest_hits_tri"] + 32.0 * sc["closest_hits_sph"]) / max(sc["rays_closest"], 1)
-        launches = cnt["launches_shadow"]
-        rays_per_launch = cnt["rays_shadow"] / launches
-        avg_ms = cnt["kernel_ms_shadow"] / launches
-        achieved = bytes_per_shadow_ray * rays_per_launch / (avg_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(a, "k_trace_p")
         roofline = {
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": None,
-            "kernel": "k_shadow<false,false> (any-hit traversal of the 8-wide occlusion BVH, one thread per light sample)",
-            "nodes_per_ray": {"wide80B": round(sc["shadow_wide"] / max(sc["rays_shadow"], 1), 2), "binary64B": round(sc["shadow_inner"] / max(sc["rays_shadow"], 1), 2),
-                              "tri48B": round(sc["shadow_tris"] / max(sc["rays_shadow"], 1), 2)},
-            "bytes_per_ray": round(bytes_per_shadow_ray, 1), "rays_per_launch": round(rays_per_launch, 1), "avg_launch_ms": round(avg_ms, 4),
+            "traffic": traffic, "traffic_source": traffic_src,
+            "kernel": kernel, "per_traced_ray": per_ray,
+            "bytes_per_ray": round(bytes_per_ray, 1), "rays_per_launch": round(rays_per_launch, 1), "avg_launch_ms": round(avg_ms, 4),
             "launches_per_step": int(launches),
-            "kernel_ms_per_step": {"k_trace_p": round(cnt["kernel_ms_shadow"], 2), "k_extend": round(cnt["kernel_ms_closest"], 2),
-                                   "k_light": round(cnt["kernel_ms_light"], 2), "shade+generate+resolve": round(cnt["kernel_ms_shade"], 2)},
+            "kernel_ms_per_step": {"k_trace_p": round(cnt["kernel_ms_shadow"], 2), "k_light+k_binary": round(cnt["kernel_ms_light"], 2),
+                                   "k_extend": round(cnt["kernel_ms_closest"], 2), "shade+generate+resolve": round(cnt["kernel_ms_shade"], 2)},
             "k_extend_bytes_per_ray": round(bytes_per_closest_ray, 1),
             "k_extend_GBps": round(bytes_per_closest_ray * cnt["rays_closest"] / max(cnt["kernel_ms_closest"], 1e-9) / 1e6, 2),
-            "note": "working set (%.0f MB) is resident in L2 / Infinity Cache: a low HBM fraction is expected (SURVEY.md §8d)" % (scene.info.device_bytes / 1e6),
+            "note": "algorithmic bytes over kernel time; the scene (%.0f MB) is resident in L2 / Infinity Cache, so this rate is served by the caches and may "
+                    "exceed the HBM peak, while `traffic` (HBM bytes per launch from the PMC counters) stays far below the algorithmic bytes "
+                    "(SURVEY.md §8d, DESIGN.md §6)" % (scene.info.device_bytes / 1e6),
         }
 
     # ---- CPU baseline: the oracle (reference algorithm, unpruned traversal, recursive integrator) on a bounded sample ----
@@ -193,6 +213,25 @@ def main():
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(a, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_pmc.json, written by
+    tools/summarize_prof.py from FETCH_SIZE / WRITE_SIZE collected in their own passes and corrected as MI355X_MICROARCH.md
+    prescribes).  bench.py cannot collect PMC counters on itself; the figure is only reported for the workload it was measured on."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc.json")
+    try:
+        with open(path) as f:
+            j = json.load(f)
+    except (OSError, ValueError):
+        return None, None
+    w = j.get("workload", {})
+    if (w.get("width"), w.get("height"), w.get("light_samples"), w.get("bounces"), w.get("mesh")) != (a.width, a.height, a.light_samples, a.bounces, a.mesh):
+        return None, None
+    k = j.get("kernels", {}).get(kernel)
+    if not k or k.get("hbm_bytes_per_launch") is None:
+        return None, None
+    return k["hbm_bytes_per_launch"], "profiles/r01_pmc.json (%s)" % j.get("source", "")
 
 
 def cpu_baseline(a, standin, dragon_obj, target_s):

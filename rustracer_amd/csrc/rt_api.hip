@@ -69,9 +69,9 @@ struct rt_scene {
     uint64_t device_bytes = 0;
 
     // workspace (grow-only; no allocation in steady state)
-    DevBuf<uint32_t> w_counts, w_hit_id;
+    DevBuf<uint32_t> w_counts, w_hit_id, w_blist;
     DevBuf<float> w_hit_t;
-    DevBuf<float4> w_ray_o[2], w_ray_d[2], w_vP, w_vN, w_contrib, w_direct, w_stackA, w_stackB, w_radiance, w_accum;
+    DevBuf<float4> w_ray_o[2], w_ray_d[2], w_vP, w_vN, w_vS, w_contrib, w_direct, w_stackA, w_stackB, w_radiance, w_accum;
     DevBuf<float2> w_svis;
     DevBuf<float4> w_lray;
     DevBuf<uint64_t> w_rng;
@@ -84,8 +84,8 @@ struct rt_scene {
     DevBuf<float> w_rays;   // scratch for arbitrary-ray calls
 
     bool opt_stats = false, opt_timing = false;
-    uint64_t opt_max_paths = 1ull << 22;
-    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 24, opt_phase_bias = 4, opt_shadow_waves = 8;
+    uint64_t opt_max_paths = 1ull << 24;
+    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 24, opt_phase_bias = 4, opt_shadow_waves = 8, opt_light_waves = 5;
     uint32_t grid_max = 2048;
 
     std::vector<EventPair> events;
@@ -341,7 +341,7 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
     const uint64_t cap_paths = (uint64_t)npix_chunk * spc;
     const uint32_t levels = P.bounces + 1;
 
-    if ((rc = s->w_counts.ensure(levels + 1))) return rc;
+    if ((rc = s->w_counts.ensure(3 * (levels + 1)))) return rc;
     for (int q = 0; q < 2; ++q) {
         if ((rc = s->w_ray_o[q].ensure(cap_paths))) return rc;
         if ((rc = s->w_ray_d[q].ensure(cap_paths))) return rc;
@@ -350,12 +350,14 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
     if ((rc = s->w_hit_t.ensure(cap_paths))) return rc;
     if ((rc = s->w_vP.ensure(cap_paths))) return rc;
     if ((rc = s->w_vN.ensure(cap_paths))) return rc;
+    if ((rc = s->w_vS.ensure(cap_paths))) return rc;
     if ((rc = s->w_rng.ensure(cap_paths))) return rc;
     const bool persist = !hemi && nlL > 0 && s->dev.n_wnodes != 0u && s->opt_persist;   // k_shadow_p over the 8-wide occlusion BVH
     const bool in_wave = !persist && nlL > 0 && nlL <= 64 && (64 % nlL) == 0;
     const uint64_t cap_slots = ((cap_paths + 63) / 64) * 64 * nlL;
     if (persist && (rc = s->w_svis.ensure(cap_slots))) return rc;
-    if (persist && (rc = s->w_lray.ensure(cap_slots))) return rc;
+    if (persist && (rc = s->w_lray.ensure(2 * cap_slots))) return rc;
+    if (persist && (rc = s->w_blist.ensure(cap_slots))) return rc;
     if (!persist && !in_wave && (rc = s->w_contrib.ensure(cap_paths * (nlL ? nlL : 1)))) return rc;
     if ((rc = s->w_direct.ensure(cap_paths))) return rc;
     if ((rc = s->w_stackA.ensure(cap_paths * (P.bounces ? P.bounces : 1)))) return rc;
@@ -370,11 +372,11 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
     pc.seed_mixed = mix64(P.seed);
     pc.tiles_x = sh.tiles_x; pc.n_tiles = sh.n_tiles;
     pc.n_groups = n_groups; pc.nlL = nlL;
-    pc.counts = s->w_counts.p;
+    pc.counts = s->w_counts.p; pc.vcounts = s->w_counts.p + (levels + 1); pc.bcounts = s->w_counts.p + 2 * (levels + 1); pc.vS = s->w_vS.p;
     for (int q = 0; q < 2; ++q) { pc.ray_o[q] = s->w_ray_o[q].p; pc.ray_d[q] = s->w_ray_d[q].p; }
     pc.hit_id = s->w_hit_id.p; pc.hit_t = s->w_hit_t.p;
     pc.vP = s->w_vP.p; pc.vN = s->w_vN.p; pc.rng = s->w_rng.p; pc.contrib = s->w_contrib.p; pc.direct = s->w_direct.p; pc.in_wave = in_wave ? 1u : 0u;
-    pc.svis = s->w_svis.p; pc.lray = s->w_lray.p; pc.persist = persist ? 1u : 0u;
+    pc.svis = s->w_svis.p; pc.lray = s->w_lray.p; pc.blist = s->w_blist.p; pc.persist = persist ? 1u : 0u;
     pc.stackA = s->w_stackA.p; pc.stackB = s->w_stackB.p; pc.radiance = s->w_radiance.p; pc.accum = s->w_accum.p;
     pc.jump = s->w_jump.p; pc.stats = s->w_stats.p; pc.rgba = rgba_dev;
 
@@ -392,7 +394,7 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
             const uint32_t spc_now = (P.spp - s0) < spc ? (P.spp - s0) : spc;
             pc.pix0 = (uint32_t)pix0; pc.npix = npix; pc.s0 = s0; pc.spc = spc_now; pc.npaths = npix * spc_now;
             s->samples += 0;   // owned, valid samples are counted on the device side via ST_RAYS (primary level)
-            HIP_TRY(hipMemsetAsync(pc.counts, 0, (levels + 1) * sizeof(uint32_t), stream));
+            HIP_TRY(hipMemsetAsync(pc.counts, 0, 3 * (levels + 1) * sizeof(uint32_t), stream));
             size_t ev;
             begin_timing(s, stream, 2, &ev);
             hipLaunchKernelGGL(k_generate, dim3(grid_for(s, pc.npaths)), dim3(RT_BLOCK), 0, stream, pc);
@@ -411,8 +413,12 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
                     const uint32_t gs = grid_for(s, (uint64_t)pc.npaths * nlL);
                     begin_timing(s, stream, hemi ? 0 : (persist ? 3 : 1), &ev);
                     if (persist) {
-                        if (s->opt_stats) hipLaunchKernelGGL(k_light<true>, dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
-                        else hipLaunchKernelGGL(k_light<false>, dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                        if (s->opt_stats) hipLaunchKernelGGL((k_light<true, 5>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                        else if (s->opt_light_waves >= 8) hipLaunchKernelGGL((k_light<false, 8>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                        else if (s->opt_light_waves >= 6) hipLaunchKernelGGL((k_light<false, 6>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                        else hipLaunchKernelGGL((k_light<false, 5>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                        if (s->opt_stats) hipLaunchKernelGGL(k_binary<true>, dim3(64), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                        else hipLaunchKernelGGL(k_binary<false>, dim3(64), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
                         end_timing(s, stream, ev);
                         begin_timing(s, stream, 1, &ev);
                         if (s->opt_stats) hipLaunchKernelGGL((k_trace_p<true, 8>), dim3(gs), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
@@ -538,9 +544,9 @@ void rt_scene_destroy(rt_scene* s) {
     if (s->uploaded) (void)hipDeviceSynchronize();
     s->d_nodes.release(); s->d_tris.release(); s->d_tri_nrm.release(); s->d_sph.release(); s->d_mats.release();
     s->d_sph_aux.release(); s->d_lights.release(); s->d_ovf.release(); s->d_wnodes.release(); s->d_wprims.release();
-    s->w_counts.release(); s->w_hit_id.release(); s->w_hit_t.release();
+    s->w_counts.release(); s->w_hit_id.release(); s->w_blist.release(); s->w_hit_t.release();
     for (int q = 0; q < 2; ++q) { s->w_ray_o[q].release(); s->w_ray_d[q].release(); }
-    s->w_vP.release(); s->w_vN.release(); s->w_contrib.release(); s->w_direct.release(); s->w_stackA.release(); s->w_stackB.release();
+    s->w_vP.release(); s->w_vN.release(); s->w_vS.release(); s->w_contrib.release(); s->w_direct.release(); s->w_stackA.release(); s->w_stackB.release();
     s->w_radiance.release(); s->w_accum.release(); s->w_svis.release(); s->w_lray.release(); s->w_rng.release(); s->w_jump.release(); s->w_stats.release();
     s->w_frame.release(); s->w_ids.release(); s->w_ts.release(); s->w_rays.release();
     for (size_t i = 0; i < s->events.size(); ++i) { (void)hipEventDestroy(s->events[i].a); (void)hipEventDestroy(s->events[i].b); }
@@ -663,6 +669,7 @@ int rt_get_counters(const rt_scene* cs, rt_counters* out) {
     if (out->rays_closest == 0 && s->launches[0] && s->samples) out->rays_closest = s->samples;   // primary cast: one ray per owned pixel
     out->closest_inner = st[ST_C_INNER]; out->closest_tris = st[ST_C_TRIS]; out->closest_sphs = st[ST_C_SPHS];
     out->shadow_inner = st[ST_S_INNER]; out->shadow_tris = st[ST_S_TRIS]; out->shadow_sphs = st[ST_S_SPHS]; out->shadow_wide = st[ST_S_WIDE];
+    for (int k = 0; k < 6; ++k) out->trace_steps[k] = st[ST_P_NODE_STEPS + k];
     out->closest_hits_tri = st[ST_HITS_TRI]; out->closest_hits_sph = st[ST_HITS_SPH];
     double ms[4] = {0, 0, 0, 0};
     for (size_t i = 0; i < s->events_used; ++i) {
@@ -679,11 +686,15 @@ int rt_set_option(rt_scene* s, const char* name, uint64_t value) {
     const std::string n(name);
     if (n == "stats") s->opt_stats = value != 0;
     else if (n == "timing") s->opt_timing = value != 0;
-    else if (n == "max_paths") s->opt_max_paths = value ? value : (1ull << 22);
+    else if (n == "max_paths") s->opt_max_paths = value ? value : (1ull << 24);
     else if (n == "self_test") { s->opt_self_test = value ? 1 : 0; s->dev.self_test = s->opt_self_test; }
     else if (n == "wide") { s->opt_wide = value ? 1 : 0; s->dev.n_wnodes = (s->wide.ok && s->opt_wide) ? s->wide.n_nodes() : 0u; }
     else if (n == "persist") s->opt_persist = value ? 1 : 0;
     else if (n == "shadow_waves") s->opt_shadow_waves = (uint32_t)value;
+    else if (n == "light_waves") s->opt_light_waves = (uint32_t)value;
+    else if (n == "persist") s->opt_persist = value ? 1 : 0;
+    else if (n == "shadow_waves") s->opt_shadow_waves = (uint32_t)value;
+    else if (n == "light_waves") s->opt_light_waves = (uint32_t)value;
     else if (n == "refill_min") { s->opt_refill_min = value > 64 ? 64 : (value < 1 ? 1 : (uint32_t)value); s->dev.refill_min = s->opt_refill_min; }
     else if (n == "phase_bias") { s->opt_phase_bias = (uint32_t)value; s->dev.phase_bias = s->opt_phase_bias; }
     else if (n == "inner_min") { s->opt_inner_min = value > 64 ? 64 : (uint32_t)value; s->dev.inner_min = s->opt_inner_min; }

@@ -33,6 +33,7 @@ namespace rt {
 #define RT_PI 3.14159265358979323846f
 #define RT_ROULETTE 0.7f         // src/raytracer.rs:11
 #define RT_INFO_BLOCKER 0x80000000u
+#define RT_CHUNK 512u           // persistent kernels: consecutive queue entries a wave takes at a time
 
 struct DevScene {
     const float4* nodes;     // 4 x float4 per inner node (64 B)
@@ -50,8 +51,8 @@ struct DevScene {
     const float4* wnodes;    // occlusion BVH (host_scene.h WideBVH): 5 x float4 per 8-wide node (80 B)
     const float4* wprims;    // 3 x float4 per blocker primitive record (48 B), in node order
     uint32_t n_wnodes;       // 0: shadow rays take the binary tree
-    uint32_t refill_min;     // k_shadow_p: idle lanes that trigger a refill of the wave
-    uint32_t phase_bias;     // k_shadow_p: node step when 4 * lanes_at_nodes >= phase_bias * lanes_at_primitives
+    uint32_t refill_min;     // k_trace_p: idle lanes that trigger a refill of the wave
+    uint32_t phase_bias;     // k_trace_p: node step when 4 * lanes_at_nodes >= phase_bias * lanes_at_primitives
 };
 
 struct TravStats {
@@ -66,18 +67,22 @@ struct PassCtx {
     uint32_t npaths;                 // npix * spc
     uint32_t n_groups, nlL;          // light-sample groups (lights, or 1 for the hemisphere estimator) and groups * light_samples
     uint32_t* counts;                // live rays per level, [bounces + 2]
+    uint32_t* vcounts;               // path vertices to light per level (rays that hit something, depth left), [bounces + 2]
+    uint32_t* bcounts;               // light-sample rays per level that must take the binary tree (k_binary), [bounces + 2]
+    uint32_t* blist;                 // their slots
+    float4* vS;                      // per vertex: (path slot bits, incoming ray direction wo)
     float4* ray_o[2];                // (origin, slot bits)   ping-pong by level parity
     float4* ray_d[2];                // (direction, 0)
     uint32_t* hit_id;
     float* hit_t;
-    float4* vP;                      // (hit point, material index bits)
-    float4* vN;                      // (shading normal, bits: hit object id + 1, 0 = path ended)
+    float4* vP;                      // per vertex, compacted by k_shade_a: (hit point, material index bits)
+    float4* vN;                      // (shading normal, bits: hit object id + 1)
     uint64_t* rng;                   // per path slot
     float4* contrib;                 // per (vertex, light sample): (rgb, visible); only when !in_wave
     float4* direct;                  // per vertex: light-sample sum (in_wave)
     uint32_t in_wave;                // nlL divides 64: k_shadow sums a vertex's light samples inside the wave
     float2* svis;                    // per light-sample slot (ls_slot), k_light: (|wi.n|, sign bit set = dead / occluded, pdf)
-    float4* lray;                    // per light-sample slot, k_light: (wi, distance to the light sample) of the rays still to trace
+    float4* lray;                    // per light-sample slot, k_light: rays still to trace, 2 x float4: (wi, distance to the light sample), (1/d of the box test, 0)
     uint32_t persist;                // light samples go through k_light + k_trace_p; k_shade_b sums pc.svis
     float4* stackA;                  // [level][slot] (direct rgb, cos)
     float4* stackB;                  // [level][slot] (reflected rgb, pdf)
@@ -89,7 +94,8 @@ struct PassCtx {
 };
 
 // traversal work is counted per ray class: [ST_C_*] closest-hit rays, [ST_S_*] shadow (any-hit) rays
-enum { ST_RAYS_CLOSEST = 0, ST_RAYS_SHADOW, ST_C_INNER, ST_C_TRIS, ST_C_SPHS, ST_S_INNER, ST_S_TRIS, ST_S_SPHS, ST_HITS_TRI, ST_HITS_SPH, ST_S_WIDE, ST_COUNT };
+enum { ST_RAYS_CLOSEST = 0, ST_RAYS_SHADOW, ST_C_INNER, ST_C_TRIS, ST_C_SPHS, ST_S_INNER, ST_S_TRIS, ST_S_SPHS, ST_HITS_TRI, ST_HITS_SPH, ST_S_WIDE,
+       ST_P_NODE_STEPS, ST_P_NODE_LANES, ST_P_PRIM_STEPS, ST_P_PRIM_LANES, ST_P_REFILLS, ST_P_REFILL_LANES, ST_COUNT };
 
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ vec3 xyz(float4 v) { return mk(v.x, v.y, v.z); }
@@ -712,30 +718,38 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_a(DevScene sc, PassCtx pc, u
     const uint32_t bounces_left = pc.P.bounces - level;
     const float4* ro = pc.ray_o[level & 1];
     const float4* rd = pc.ray_d[level & 1];
-    __shared__ uint32_t s_tmp[RT_BLOCK / 64];
+    __shared__ uint32_t s_tmp[RT_BLOCK / 64 + 1];
     uint32_t n_alive = 0, n_alive_tri = 0;
-    for (uint32_t e = blockIdx.x * RT_BLOCK + threadIdx.x; e < n; e += gridDim.x * RT_BLOCK) {
-        const float4 o4 = ro[e];
-        const uint32_t slot = __float_as_uint(o4.w);
-        const uint32_t id = pc.hit_id[e];
+    // rays that found a surface to light are compacted into the vertex queue (misses and depth-0 hits end here)
+    for (uint32_t e0 = blockIdx.x * RT_BLOCK; e0 < n; e0 += gridDim.x * RT_BLOCK) {
+        const uint32_t e = e0 + threadIdx.x;
         bool alive = false;
-        if (id == RT_MISS) {
-            fold_path(pc, slot, level, mk(0.0f, 0.0f, 0.0f));                      // raytracer.rs:348
-        } else {
-            const uint32_t mat = object_info(sc, id) & ~RT_INFO_BLOCKER;
-            if (bounces_left == 0) {
-                fold_path(pc, slot, level, xyz(sc.mats[2 * mat + 1]));             // zero_bounce_radiance, raytracer.rs:245-247
+        float4 vp = make_float4(0, 0, 0, 0), vn = vp, vs = vp;
+        uint32_t id = RT_MISS;
+        if (e < n) {
+            const float4 o4 = ro[e];
+            const uint32_t slot = __float_as_uint(o4.w);
+            id = pc.hit_id[e];
+            if (id == RT_MISS) {
+                fold_path(pc, slot, level, mk(0.0f, 0.0f, 0.0f));                      // raytracer.rs:348
             } else {
-                const vec3 o = xyz(o4), d = xyz(rd[e]);
-                const float min_dist = pc.hit_t[e] - RT_EPS;                       // RayIntersection::point, mod.rs:58-62
-                const vec3 p = add(o, scale(d, min_dist));
-                const vec3 nrm = surface_normal(sc, id, p);
-                pc.vP[e] = make_float4(p.x, p.y, p.z, __uint_as_float(mat));
-                pc.vN[e] = make_float4(nrm.x, nrm.y, nrm.z, __uint_as_float(id + 1u));
-                alive = true;
+                const uint32_t mat = object_info(sc, id) & ~RT_INFO_BLOCKER;
+                if (bounces_left == 0) {
+                    fold_path(pc, slot, level, xyz(sc.mats[2 * mat + 1]));             // zero_bounce_radiance, raytracer.rs:245-247
+                } else {
+                    const vec3 o = xyz(o4), d = xyz(rd[e]);
+                    const float min_dist = pc.hit_t[e] - RT_EPS;                       // RayIntersection::point, mod.rs:58-62
+                    const vec3 p = add(o, scale(d, min_dist));
+                    const vec3 nrm = surface_normal(sc, id, p);
+                    vp = make_float4(p.x, p.y, p.z, __uint_as_float(mat));
+                    vn = make_float4(nrm.x, nrm.y, nrm.z, __uint_as_float(id + 1u));
+                    vs = make_float4(o4.w, d.x, d.y, d.z);
+                    alive = true;
+                }
             }
         }
-        if (!alive) pc.vN[e] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const uint32_t q = block_append(alive, &pc.vcounts[level], s_tmp);
+        if (alive) { pc.vP[q] = vp; pc.vN[q] = vn; pc.vS[q] = vs; }
         n_alive += alive ? 1u : 0u;
         n_alive_tri += (alive && id < sc.n_tri) ? 1u : 0u;
     }
@@ -761,8 +775,7 @@ template <bool STATS, bool HEMI>
 __global__ void __launch_bounds__(RT_BLOCK, RT_SHADOW_WAVES) k_shadow(DevScene sc, PassCtx pc, uint32_t level) {
     RT_STACK_DECL;
     TravStats tst = {0, 0, 0, 0};
-    const uint32_t n = pc.counts[level] * pc.nlL;
-    const float4* ro = pc.ray_o[level & 1];
+    const uint32_t n = pc.vcounts[level] * pc.nlL;
     const uint32_t L = pc.P.light_samples;
     uint32_t* red = s_stack;   // rows 0..3 of this wave's own (then empty) stack columns: red[k * RT_BLOCK + thread] = component k
     for (uint32_t r = blockIdx.x * RT_BLOCK + threadIdx.x; r < n; r += gridDim.x * RT_BLOCK) {
@@ -775,7 +788,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SHADOW_WAVES) k_shadow(DevScene s
         vec3 wi = mk(0.0f, 0.0f, 1.0f), c = mk(0.0f, 0.0f, 0.0f), reflected = mk(0.0f, 0.0f, 0.0f);
         float d_s = 0.0f, cos_theta = 0.0f;
         if (alive) {
-            const uint32_t slot = __float_as_uint(ro[e].w);
+            const uint32_t slot = __float_as_uint(pc.vS[e].x);
             const ulonglong2 jm = pc.jump[j];
             uint64_t rng = jm.x * pc.rng[slot] + jm.y;
             const float4 m0 = sc.mats[2 * __float_as_uint(P4.w)];
@@ -858,29 +871,22 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SHADOW_WAVES) k_shadow(DevScene s
 __device__ __forceinline__ size_t ls_slot(uint32_t e, uint32_t j, uint32_t nlL) {
     return (size_t)(e >> 6) * (64u * (size_t)nlL) + (size_t)j * 64u + (e & 63u);
 }
-__device__ __forceinline__ uint32_t ls_vertex(size_t slot, uint32_t nlL) {
-    const size_t tile = slot / (64u * (size_t)nlL);
-    return (uint32_t)(tile * 64u + (slot & 63u));
-}
-
-template <bool STATS>
-__global__ void __launch_bounds__(RT_BLOCK) k_light(DevScene sc, PassCtx pc, uint32_t level) {
-    RT_STACK_DECL;
+template <bool STATS, int WAVES>   // WAVES: waves per SIMD the register budget is sized for
+__global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx pc, uint32_t level) {
     TravStats tst = {0, 0, 0, 0};
-    const uint32_t n = pc.counts[level], n_round = (n + 63u) & ~63u;
-    const float4* ro = pc.ray_o[level & 1];
+    const uint32_t n = pc.vcounts[level], n_round = (n + 63u) & ~63u;
     const uint32_t nlL = pc.nlL, L = pc.P.light_samples;
     uint32_t* flags = reinterpret_cast<uint32_t*>(pc.svis);
     for (uint32_t e = blockIdx.x * RT_BLOCK + threadIdx.x; e < n_round; e += gridDim.x * RT_BLOCK) {
         float4 N4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (e < n) N4 = pc.vN[e];
-        if (__float_as_uint(N4.w) == 0u) {                       // path ended at this level (or padding of the last tile)
+        if (__float_as_uint(N4.w) == 0u) {                       // padding of the last tile
             for (uint32_t j = 0; j < nlL; ++j) flags[2 * ls_slot(e, j, nlL)] = 0x80000000u;
             continue;
         }
         const float4 P4 = pc.vP[e];
         const vec3 p = xyz(P4), nrm = xyz(N4);
-        const uint64_t rng0 = pc.rng[__float_as_uint(ro[e].w)];
+        const uint64_t rng0 = pc.rng[__float_as_uint(pc.vS[e].x)];
         // the object the rays start on, fetched once per vertex (see self_blocks())
         const uint32_t self_obj = sc.self_test ? __float_as_uint(N4.w) - 1u : RT_MISS;
         bool self_is_tri = false, self_is_sph = false;
@@ -925,17 +931,43 @@ __global__ void __launch_bounds__(RT_BLOCK) k_light(DevScene sc, PassCtx pc, uin
                 }
                 blocked = ok && t > 0.0f && t < d_s;
             }
-            if (__ballot(binary) != 0ull) {
-                // 0 * inf = NaN cases of the slab test, or far-away coordinates: settled right here on the binary tree, which
-                // has the crate's NaN behaviour (k_trace_p skips these rays)
-                bool occ = false;
-                traverse<1, STATS>(sc, binary, p, wi, d_s, self_obj, st, nullptr, nullptr, &occ, &tst);
-                if (binary) blocked = occ;
-            }
             const size_t sl = ls_slot(e, j, nlL);
             pc.svis[sl] = make_float2(__uint_as_float(__float_as_uint(cos_theta) | (blocked ? 0x80000000u : 0u)), pdf);
-            if (!blocked) pc.lray[sl] = make_float4(wi.x, wi.y, wi.z, d_s);
+            // 0 * inf = NaN cases of the slab test, or far-away coordinates: k_binary settles these few on the binary tree, which
+            // has the crate's NaN behaviour; k_trace_p recognises them by their 1/d and skips them
+            if (binary) pc.blist[atomicAdd(&pc.bcounts[level], 1u)] = (uint32_t)sl;
+            if (!blocked) {
+                pc.lray[2 * sl] = make_float4(wi.x, wi.y, wi.z, d_s);
+                pc.lray[2 * sl + 1] = make_float4(br.ix, br.iy, br.iz, 0.0f);
+            }
         }
+    }
+    flush_stats<STATS>(pc.stats, tst, ST_S_INNER);
+}
+
+// The light-sample rays k_light put on pc.blist (normally none): Scene::is_occluded on the binary tree, self test included.
+template <bool STATS>
+__global__ void __launch_bounds__(RT_BLOCK) k_binary(DevScene sc, PassCtx pc, uint32_t level) {
+    RT_STACK_DECL;
+    TravStats tst = {0, 0, 0, 0};
+    const uint32_t n = pc.bcounts[level], nlL = pc.nlL;
+    uint32_t* flags = reinterpret_cast<uint32_t*>(pc.svis);
+    for (uint32_t i0 = blockIdx.x * RT_BLOCK + (threadIdx.x & ~63u); i0 < n; i0 += gridDim.x * RT_BLOCK) {
+        const uint32_t i = i0 + (threadIdx.x & 63u);
+        const bool have = i < n;
+        vec3 o = mk(0.0f, 0.0f, 0.0f), d = mk(0.0f, 0.0f, 1.0f);
+        float max_dist = 0.0f;
+        uint32_t self_obj = RT_MISS, sl = 0u;
+        if (have) {
+            sl = pc.blist[i];
+            const uint32_t e = sl / (64u * nlL) * 64u + (sl & 63u);
+            const float4 R4 = pc.lray[2 * (size_t)sl];
+            o = xyz(pc.vP[e]); d = xyz(R4); max_dist = R4.w;
+            if (sc.self_test) self_obj = __float_as_uint(pc.vN[e].w) - 1u;
+        }
+        bool occ = false;
+        traverse<1, STATS>(sc, have, o, d, max_dist, self_obj, st, nullptr, nullptr, &occ, &tst);
+        if (have && occ) flags[2 * (size_t)sl] |= 0x80000000u;
     }
     flush_stats<STATS>(pc.stats, tst, ST_S_INNER);
 }
@@ -943,7 +975,6 @@ __global__ void __launch_bounds__(RT_BLOCK) k_light(DevScene sc, PassCtx pc, uin
 // Wave state of k_trace_p: a wave owns chunks of RT_CHUNK consecutive slots (chunk = wave index, then
 // + number of waves), reads them a row of 64 at a time, and hands the live rays of a row to its idle
 // lanes as they become free (`pend` = live rays of the current row not yet handed out).
-#define RT_CHUNK 512u
 template <bool STATS, int WAVES>   // WAVES: waves per SIMD the register budget is sized for
 __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCtx pc, uint32_t level) {
     RT_STACK_DECL;
@@ -951,16 +982,19 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
     uint32_t* pub = s_pub + (threadIdx.x & ~63u);
     TravStats tst = {0, 0, 0, 0};
     const uint32_t nlL = pc.nlL;
-    const uint32_t n_slots = ((pc.counts[level] + 63u) >> 6) * 64u * nlL;      // < 2^31 (render_impl caps paths * nlL at 2^30)
+    const uint32_t n_slots = ((pc.vcounts[level] + 63u) >> 6) * 64u * nlL;      // < 2^31 (render_impl caps paths * nlL at 2^30)
     const uint32_t n_waves = gridDim.x * (RT_BLOCK / 64);
     const uint32_t lane = __lane_id();
     uint32_t chunk = __builtin_amdgcn_readfirstlane((blockIdx.x * RT_BLOCK + threadIdx.x) >> 6);
     uint32_t next = chunk * RT_CHUNK;
     uint32_t chunk_end = next < n_slots ? (n_slots - next < RT_CHUNK ? n_slots : next + RT_CHUNK) : next;
     unsigned long long pend = 0ull;
-    uint32_t row_base = 0u;
+    uint32_t row_base = 0u, row_tile = 0u;                                     // current row: first slot, vertex tile (vertex = row_tile * 64 + lane)
+    uint32_t tile = next / (64u * nlL), jrow = (next >> 6) % nlL;              // tile and light sample of the row at `next`
     const uint32_t refill_min = sc.refill_min, phase_bias = sc.phase_bias;
     uint32_t* flags = reinterpret_cast<uint32_t*>(pc.svis);
+
+    uint32_t w_steps[6] = {0, 0, 0, 0, 0, 0};   // STATS: wave steps and the lanes that took part (node, primitive, refill)
 
     // the ray this lane is tracing (cur != 0)
     uint32_t cur = 0u, slot = 0u, cos_bits = 0u;
@@ -976,11 +1010,15 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
                 const uint32_t f = flags[2 * (size_t)(next + lane)];
                 pend = __ballot(!(f & 0x80000000u));
                 row_base = next;
+                row_tile = tile;
                 next += 64u;
+                if (++jrow == nlL) { jrow = 0u; ++tile; }
                 if (next == chunk_end) {
                     chunk += n_waves;
                     next = chunk * RT_CHUNK;
                     chunk_end = next < n_slots ? (n_slots - next < RT_CHUNK ? n_slots : next + RT_CHUNK) : next;
+                    tile = next / (64u * nlL);
+                    jrow = (next >> 6) % nlL;
                 }
                 if (pend == 0ull) continue;
             }
@@ -988,22 +1026,26 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
             const uint32_t take = n_pend < n_idle ? n_pend : n_idle;
             const bool offered = ((pend >> lane) & 1ull) != 0ull;
             const uint32_t prank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pend >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pend, 0u));
-            if (offered && prank < take) pub[prank] = row_base + lane;
+            if (offered && prank < take) pub[prank] = lane;
             pend = __ballot(offered && prank >= take);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const uint32_t irank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
             const bool mine = cur == 0u && irank < take;
+            if (STATS) { w_steps[4]++; w_steps[5] += take; }
             if (mine) {
-                slot = pub[irank];
-                const uint32_t e = ls_vertex(slot, nlL);
-                const float4 R4 = pc.lray[slot];
+                const uint32_t src = pub[irank];
+                slot = row_base + src;
+                const uint32_t e = row_tile * 64u + src;
+                const float4 R4 = pc.lray[2 * (size_t)slot], I4 = pc.lray[2 * (size_t)slot + 1];
                 const float4 P4 = pc.vP[e];
                 cos_bits = flags[2 * (size_t)slot];
                 o = xyz(P4); d = xyz(R4); max_dist = R4.w;
-                br = make_box_ray(o, d);
+                br.ox = o.x; br.oy = o.y; br.oz = o.z;
+                br.ix = I4.x; br.iy = I4.y; br.iz = I4.z;                     // make_box_ray(o, d), computed by k_light
+                br.sx = I4.x < 0.0f; br.sy = I4.y < 0.0f; br.sz = I4.z < 0.0f; // sign of the normalised direction (finite 1/d only: wide_ray_ok)
                 lim = prune_limit(max_dist);
-                if (wide_ray_ok(br, o)) {      // the others were settled by k_light on the binary tree
+                if (wide_ray_ok(br, o)) {      // the others are k_binary's
                     cur = 1u;                  // inner group {node 0}
                     st.sp = 0;
                 }
@@ -1016,20 +1058,22 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
         const bool at_prim = (cur & RT_W_PRIM) != 0u;
         const uint32_t n_node = (uint32_t)__popcll(__ballot(at_node)), n_prim = (uint32_t)__popcll(__ballot(at_prim));
         if (n_node != 0u && (n_prim == 0u || 4u * n_node >= phase_bias * n_prim)) {
+            if (STATS) { w_steps[0]++; w_steps[1] += n_node; }
             if (at_node) wide_node_step<STATS>(sc, br, lim, cur, st, &tst);
-        } else if (at_prim) {
-            if (wide_prim_step<STATS>(sc, br, o, d, max_dist, cur, st, &tst)) flags[2 * (size_t)slot] = cos_bits | 0x80000000u;
+        } else {
+            if (STATS) { w_steps[2]++; w_steps[3] += n_prim; }
+            if (at_prim && wide_prim_step<STATS>(sc, br, o, d, max_dist, cur, st, &tst)) flags[2 * (size_t)slot] = cos_bits | 0x80000000u;
         }
     }
     flush_stats<STATS>(pc.stats, tst, ST_S_INNER);
+    if (STATS && lane == 0u)
+        for (int k = 0; k < 6; ++k) atomicAdd(&pc.stats[ST_P_NODE_STEPS + k], (unsigned long long)w_steps[k]);
 }
 
 // The rest of one_bounce_radiance_importance and global_illumination (src/raytracer.rs:282-326).
 __global__ void __launch_bounds__(RT_BLOCK) k_shade_b(DevScene sc, PassCtx pc, uint32_t level) {
-    const uint32_t n = pc.counts[level];
+    const uint32_t n = pc.vcounts[level];
     const uint32_t bounces_left = pc.P.bounces - level;
-    const float4* ro = pc.ray_o[level & 1];
-    const float4* rd = pc.ray_d[level & 1];
     float4* no = pc.ray_o[(level + 1) & 1];
     float4* nd = pc.ray_d[(level + 1) & 1];
     const uint32_t L = pc.P.light_samples;
@@ -1042,24 +1086,29 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_b(DevScene sc, PassCtx pc, u
         float4 o_next = make_float4(0, 0, 0, 0), d_next = make_float4(0, 0, 0, 0);
         if (e < n) {
             const float4 N4 = pc.vN[e];
-            if (__float_as_uint(N4.w) != 0u) {
-                const float4 P4 = pc.vP[e];
-                const uint32_t slot = __float_as_uint(ro[e].w);
+            {
+                const float4 P4 = pc.vP[e], S4 = pc.vS[e];
+                const uint32_t slot = __float_as_uint(S4.x);
                 const uint32_t mat = __float_as_uint(P4.w);
                 const float4 m0 = sc.mats[2 * mat], m1 = sc.mats[2 * mat + 1];
                 const vec3 p = xyz(P4), nrm = xyz(N4);
                 vec3 l = mk(0.0f, 0.0f, 0.0f);
                 if (pc.persist) {
-                    // one_bounce_radiance_importance's sample loop (raytracer.rs:266-283) over what k_shadow_p left per ray
+                    // one_bounce_radiance_importance's sample loop (raytracer.rs:266-283) over what k_light / k_trace_p left per ray
                     const vec3 f = __float_as_uint(m0.x) == RT_BSDF_DIFFUSE ? scale(mk(m0.y, m0.z, m0.w), 1.0f / RT_PI) : mk(0.0f, 0.0f, 0.0f);   // Object::bsdf
                     for (uint32_t g = 0; g < pc.n_groups; ++g) {
                         const uint32_t light = sc.lights[g];
                         const vec3 le = xyz(sc.mats[2 * (sc.sph_aux[light - sc.n_tri].y & ~RT_INFO_BLOCKER) + 1]);
                         const vec3 base = mul3(le, f);
                         vec3 color = mk(0.0f, 0.0f, 0.0f);
-                        for (uint32_t s = 0; s < L; ++s) {
-                            const float2 v = pc.svis[ls_slot(e, g * L + s, pc.nlL)];
-                            if (!(__float_as_uint(v.x) & 0x80000000u)) color = add(color, scale(scale(base, v.x), v.y));   // raytracer.rs:279
+                        const float2* vp = pc.svis + ls_slot(e, g * L, pc.nlL);       // sample s of this vertex: vp[64 * s]
+                        for (uint32_t s0 = 0; s0 < L; s0 += 8) {                         // 8 loads in flight, then added in sample order
+                            float2 v[8];
+#pragma unroll
+                            for (uint32_t k = 0; k < 8; ++k) v[k] = vp[64 * (size_t)(s0 + k < L ? s0 + k : L - 1)];
+#pragma unroll
+                            for (uint32_t k = 0; k < 8; ++k)
+                                if (s0 + k < L && !(__float_as_uint(v[k].x) & 0x80000000u)) color = add(color, scale(scale(base, v[k].x), v[k].y));   // raytracer.rs:279
                         }
                         l = add(l, scale(color, inv_light_samples));                // raytracer.rs:282
                     }
@@ -1085,7 +1134,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_b(DevScene sc, PassCtx pc, u
                     if (!(next_f32(&rng) <= RT_ROULETTE)) {                         // weighted_coin_flip, common.rs:136-138
                         fold_path(pc, slot, level, l);
                     } else {
-                        const vec3 wo = xyz(rd[e]);
+                        const vec3 wo = mk(S4.y, S4.z, S4.w);
                         vec3 wi, reflected;
                         float pdf;
                         const vec3 refl = mk(m0.y, m0.z, m0.w);

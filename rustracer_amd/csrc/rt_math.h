@@ -86,11 +86,15 @@ RT_HD float acos_f(float xf) {
     if (x != x) return xf;
     if (x >= 1.0) return x == 1.0 ? 0.0f : bits_to_float(0x7fc00000u);
     if (x <= -1.0) return x == -1.0 ? (float)PI_D : bits_to_float(0x7fc00000u);
+    // One evaluation of the rational for both ranges (a wave holds lanes of both): the operations applied to
+    // each value are those of the two-branch form, so the result is the same bit pattern.
     const double ax = x < 0.0 ? -x : x;
-    if (ax <= 0.5) return (float)(PIO2_D - (x + x * asin_ratio(x * x)));
-    const double z = (1.0 - ax) * 0.5;
+    const bool small = ax <= 0.5;
+    const double z = small ? x * x : (1.0 - ax) * 0.5;
+    const double r = asin_ratio(z);
+    if (small) return (float)(PIO2_D - (x + x * r));
     const double s = sqrt(z);
-    const double w = s + s * asin_ratio(z);
+    const double w = s + s * r;
     if (x > 0.0) return (float)(2.0 * w);
     return (float)(PI_D - 2.0 * w);
 }

@@ -214,7 +214,7 @@ def test_render_independent_of_pass_size_and_shards(scenes):
         gsc.set_option("max_paths", max_paths)
         got, _ = gpu_render(gsc, p)
         assert np.array_equal(got, ref), "max_paths=%d" % max_paths
-    gsc.set_option("max_paths", 1 << 22)
+    gsc.set_option("max_paths", 0)                        # back to the default
     from rustracer_amd._lib import check, lib, ptr
     frame = np.zeros((72, 80, 4), np.uint8)
     total_samples = 0

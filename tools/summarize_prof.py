@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
-"""Summarise a tools/profile.sh output directory (rocprofv3 CSVs) into one markdown file for profiles/.
+"""Summarise a tools/profile.sh output directory (rocprofv3 CSVs) into one markdown file for profiles/,
+and optionally the per-launch HBM traffic of each kernel into a JSON that bench.py reads for `roofline.traffic`.
 
-    python tools/summarize_prof.py gpurun_out/prof_<tag> profiles/<name>.md
+    python tools/summarize_prof.py gpurun_out/prof_<tag> profiles/<name>.md [profiles/r01_pmc.json width height light_samples bounces mesh]
 """
+import json
 import csv
 import glob
 import os
@@ -18,7 +20,7 @@ def short(name):
 
 def main(src, dst):
     out = ["# rocprofv3 summary: %s" % os.path.basename(src.rstrip("/")), ""]
-    for line in open(os.path.join(src, "trace.log")):
+    for line in (open(os.path.join(src, "trace.log")) if os.path.exists(os.path.join(src, "trace.log")) else []):
         if line.startswith("{"):
             out += ["bench line of the traced run:", "", "```", line.strip(), "```", ""]
     stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
@@ -66,7 +68,42 @@ def main(src, dst):
     os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
     open(dst, "w").write("\n".join(out) + "\n")
     print("\n".join(out))
+    return agg, calls
+
+
+def write_pmc_json(agg, calls, src, path, workload):
+    """HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) KiB / dispatches: FETCH_SIZE and WRITE_SIZE come from separate --pmc
+    passes; on gfx950 FETCH_SIZE tallies the 128-B requests of 16-B-per-lane loads at 64 B, so it is doubled (MI355X_MICROARCH.md, HBM)."""
+    kernels = {}
+    for k in agg:
+        a = agg[k]
+        if "FETCH_SIZE" not in a or "WRITE_SIZE" not in a:
+            continue
+        nf, nw = calls[k]["FETCH_SIZE"], calls[k]["WRITE_SIZE"]
+        fetch = a["FETCH_SIZE"] * 1024 * 2 / max(nf, 1)
+        write = a["WRITE_SIZE"] * 1024 / max(nw, 1)
+        base = k.split("<")[0]
+        e = kernels.setdefault(base, {"variants": [], "dispatches": 0, "hbm_bytes_per_launch": 0.0, "fetch_bytes_per_launch": 0.0, "write_bytes_per_launch": 0.0})
+        # several template variants of one kernel: weight by dispatch count
+        tot = e["dispatches"] + nf
+        e["fetch_bytes_per_launch"] = (e["fetch_bytes_per_launch"] * e["dispatches"] + fetch * nf) / tot
+        e["write_bytes_per_launch"] = (e["write_bytes_per_launch"] * e["dispatches"] + write * nf) / tot
+        e["dispatches"] = tot
+        e["variants"].append(k)
+        if "TCC_HIT_sum" in a:
+            e["l2_hit_rate"] = round(a["TCC_HIT_sum"] / max(a["TCC_HIT_sum"] + a.get("TCC_MISS_sum", 0), 1), 4)
+    for e in kernels.values():
+        e["hbm_bytes_per_launch"] = round(e["fetch_bytes_per_launch"] + e["write_bytes_per_launch"])
+        e["fetch_bytes_per_launch"] = round(e["fetch_bytes_per_launch"])
+        e["write_bytes_per_launch"] = round(e["write_bytes_per_launch"])
+    j = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of tools/profile.sh, %s" % os.path.basename(src.rstrip("/")),
+         "correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950 counts 128-B requests as 64 B) + WRITE_SIZE KiB x 1024, averaged over the kernel's dispatches",
+         "workload": workload, "kernels": kernels}
+    open(path, "w").write(json.dumps(j, indent=1) + "\n")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    agg_, calls_ = main(sys.argv[1], sys.argv[2])
+    if len(sys.argv) >= 9:
+        write_pmc_json(agg_, calls_, sys.argv[1], sys.argv[3],
+                       {"width": int(sys.argv[4]), "height": int(sys.argv[5]), "light_samples": int(sys.argv[6]), "bounces": int(sys.argv[7]), "mesh": sys.argv[8]})
