@@ -66,8 +66,9 @@ int main(int argc, char** argv) {
 
         // background render + interrupt (canvas.rs:241-289: every key action interrupts first)
         rt.update_render_settings(64, 16, 8);
+        rt.inner->render_progress.store(55);                                 // sentinel: do_render stores 0 first and 100 last
         rt.render(false);
-        for (int k = 0; k < 2000 && !rt.inner->is_rendering.load() && rt.inner->render_progress.load() != 100; ++k)   // bounded: the render may already be over
+        for (int k = 0; k < 5000 && !rt.inner->is_rendering.load() && rt.inner->render_progress.load() == 55; ++k)   // bounded: the render may already be over
             std::this_thread::sleep_for(std::chrono::milliseconds(1));
         rt.interrupt_render();
         rt.wait();
