@@ -993,6 +993,8 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
     uint32_t tile = next / (64u * nlL), jrow = (next >> 6) % nlL;              // tile and light sample of the row at `next`
     const uint32_t refill_min = sc.refill_min, phase_bias = sc.phase_bias;
     uint32_t* flags = reinterpret_cast<uint32_t*>(pc.svis);
+    // flags of the row at `next`, loaded one refill ahead so that a refill waits for one memory round trip, not two
+    uint32_t f_next = next < n_slots ? flags[2 * (size_t)(next + lane)] : 0x80000000u;
 
     uint32_t w_steps[6] = {0, 0, 0, 0, 0, 0};   // STATS: wave steps and the lanes that took part (node, primitive, refill)
 
@@ -1007,8 +1009,7 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
         const uint32_t n_idle = (uint32_t)__popcll(idle);
         if ((pend != 0ull || next < n_slots) && n_idle >= refill_min) {
             if (pend == 0ull) {                                  // next row of 64 slots: which rays are still to trace
-                const uint32_t f = flags[2 * (size_t)(next + lane)];
-                pend = __ballot(!(f & 0x80000000u));
+                pend = __ballot(!(f_next & 0x80000000u));
                 row_base = next;
                 row_tile = tile;
                 next += 64u;
@@ -1020,6 +1021,7 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
                     tile = next / (64u * nlL);
                     jrow = (next >> 6) % nlL;
                 }
+                f_next = next < n_slots ? flags[2 * (size_t)(next + lane)] : 0x80000000u;   // no wave but this one writes the flags of its rows
                 if (pend == 0ull) continue;
             }
             const uint32_t n_pend = (uint32_t)__popcll(pend);
