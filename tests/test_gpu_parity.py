@@ -204,6 +204,61 @@ def test_render_matches_oracle(scenes, name, w, h, spp, L, b, est):
     assert ndiff == 0, "%d of %d bytes differ (PSNR %.1f dB)" % (ndiff, got.size, psnr(got, ref["rgba"]))
 
 
+def _two_light_scene():
+    """A raw object list (rt_scene_create / Scene::new): the teapot scene's objects plus a second, coloured lamp and a mirror
+    sphere, so that one_bounce_radiance_importance loops over two lights (raytracer.rs:266) and an emissive sphere sits inside
+    the box (never a blocker, mod.rs:481)."""
+    from oracle import binding as ob
+    import rustracer_amd as ra
+    e = ra.Scene.new_specular().export()
+    mats = np.concatenate([e["mats"], np.zeros((2, 8), np.uint32)])
+    lamp2 = np.array([0, 0, 0, 0, 0.9, 0.5, 0.2, 0], np.float32)          # diffuse, black reflectance, emittance (0.9, 0.5, 0.2)
+    mirror = np.array([0, 0.9, 0.9, 0.9, 0, 0, 0, 0], np.float32)
+    mats[-2] = lamp2.view(np.uint32); mats[-2][0] = 0
+    mats[-1] = mirror.view(np.uint32); mats[-1][0] = 1
+    sph = np.concatenate([e["sph"], np.array([[-12.0, -4.0, -40.0, 3.0], [9.0, 6.0, -52.0, 4.0]], np.float32)])
+    sph_mat = np.concatenate([e["sph_mat"], np.array([len(mats) - 2, len(mats) - 1], np.uint32)])
+    args = (e["tri_pos"], e["tri_nrm"], e["tri_mat"], sph, sph_mat, mats)
+    return ob.OracleScene.raw(*args), ra.Scene.from_arrays(*args)
+
+
+@pytest.mark.parametrize("w,h,spp,L,b,cam", [(72, 56, 4, 3, 6, (0.0, 0.0, 0.0)), (64, 64, 3, 5, 4, (2.0, -4.0, -6.0)), (40, 40, 2, 32, 3, (0.0, 0.0, 0.0)),
+                                             (33, 47, 2, 70, 2, (0.0, 0.0, 0.0))])
+def test_two_lights_odd_sample_counts_and_moved_camera(gpu, w, h, spp, L, b, cam):
+    """lights x light_samples = 6, 10, 64, 140 slots per vertex (not powers of two, more than a wave), camera off the origin
+    (Raytracer::move_camera, raytracer.rs:477-481): image and ray counts identical to the oracle."""
+    osc, gsc = _two_light_scene()
+    assert list(gsc.light_indexes()) == [10, 13]
+    op = oracle_params(width=w, height=h, spp=spp, light_samples=L, bounces=b, cam=cam, seed=99)
+    ref = osc.render(op)
+    got, cnt = gpu_render(gsc, to_rt_params(op))
+    assert cnt["rays_closest"] == ref["intersect_calls"] and cnt["rays_shadow"] == ref["occluded_calls"]
+    assert np.array_equal(got, ref["rgba"]), "%d bytes differ" % int((got != ref["rgba"]).sum())
+    for opt in ("persist", "wide"):                      # the one-thread-per-ray kernel and the binary tree give the same image
+        gsc.set_option(opt, 0)
+        alt, _ = gpu_render(gsc, to_rt_params(op))
+        gsc.set_option(opt, 1)
+        assert np.array_equal(alt, ref["rgba"]), opt
+
+
+def test_axis_aligned_shadow_rays_take_the_binary_tree(gpu):
+    """Light sampling almost never produces a direction with a zero component, so Scene::is_occluded is driven directly:
+    rays with zero, denormal and tiny direction components (the 0 * inf = NaN cases of the slab test, which leave the 8-wide
+    tree for the binary one) next to ordinary ones, some starting exactly on wall planes."""
+    osc, gsc = _two_light_scene()
+    rng = np.random.default_rng(3)
+    n = 4096
+    org = rng.uniform([-19, -19, -66], [19, 19, 0], (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    d[0::4, rng.integers(3)] = 0.0
+    d[1::8, 2] = np.float32(1e-44)
+    d[2::8, 0] = np.float32(-2e-13)
+    org[3::16] = np.float32(20.0) * np.sign(org[3::16])              # origins exactly on wall planes
+    md = rng.uniform(0.5, 80, n).astype(np.float32)
+    assert np.array_equal(gsc.occluded_rays(org, d, md), osc.occluded_rays(org, d, md))
+
+
 def test_render_independent_of_pass_size_and_shards(scenes):
     """Chunking samples/pixels into passes and splitting tiles over shards never changes a pixel."""
     osc, gsc = scenes("teapot")
