@@ -903,16 +903,18 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
         }
         const float bmnx = lo3(A.x, B.x, C.x), bmny = lo3(A.y, B.y, C.y), bmnz = lo3(A.z, B.z, C.z);
         const float bmxx = hi3(A.x, B.x, C.x), bmxy = hi3(A.y, B.y, C.y), bmxz = hi3(A.z, B.z, C.z);
-        for (uint32_t j = 0; j < nlL; ++j) {
+        size_t sl = ls_slot(e, 0, nlL);                                        // slot of sample j: + 64 per sample
+        for (uint32_t g = 0, j = 0; g < pc.n_groups; ++g) {                    // for light in lights (raytracer.rs:266): per-light values stay in registers
+          const uint32_t light = sc.lights[g];
+          const float4 cr = sc.sph[light - sc.n_tri];
+          const float d_c = length3(sub(xyz(cr), p));
+          for (uint32_t ls = 0; ls < L; ++ls, ++j, sl += 64) {                 // for _ in 0..light_samples (raytracer.rs:269)
             const ulonglong2 jm = pc.jump[j];
             uint64_t rng = jm.x * rng0 + jm.y;
-            const uint32_t light = sc.lights[j / L];
-            const float4 cr = sc.sph[light - sc.n_tri];
             const vec3 sp = add(xyz(cr), scale(random_sphere(&rng), cr.w));      // Sphere::random_point, objects.rs:223-226
             const vec3 ps = sub(sp, p);
             const float d_s = length3(ps);
             const vec3 wi = scale(ps, 1.0f / d_s);
-            const float d_c = length3(sub(xyz(cr), p));
             const float cos_a = (d_c * d_c + cr.w * cr.w - d_s * d_s) / (2.0f * d_c * cr.w);
             const float pdf = 2.0f * RT_PI * (1.0f - cos_a);
             const float cos_theta = fabsf(dot3(wi, nrm));
@@ -931,7 +933,6 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
                 }
                 blocked = ok && t > 0.0f && t < d_s;
             }
-            const size_t sl = ls_slot(e, j, nlL);
             pc.svis[sl] = make_float2(__uint_as_float(__float_as_uint(cos_theta) | (blocked ? 0x80000000u : 0u)), pdf);
             // 0 * inf = NaN cases of the slab test, or far-away coordinates: k_binary settles these few on the binary tree, which
             // has the crate's NaN behaviour; k_trace_p recognises them by their 1/d and skips them
@@ -940,6 +941,7 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
                 pc.lray[2 * sl] = make_float4(wi.x, wi.y, wi.z, d_s);
                 pc.lray[2 * sl + 1] = make_float4(br.ix, br.iy, br.iz, 0.0f);
             }
+          }
         }
     }
     flush_stats<STATS>(pc.stats, tst, ST_S_INNER);
