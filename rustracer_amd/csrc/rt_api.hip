@@ -325,45 +325,51 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
     if (nlL64 >= (1ull << 24)) return fail(RT_ERR_LIMIT, "lights * light_samples too large");
     const uint32_t nlL = (uint32_t)nlL64;
 
-    uint64_t max_paths = s->opt_max_paths;
     const uint64_t cap_by_rays = (1ull << 30) / (nlL ? nlL : 1);
-    if (max_paths > cap_by_rays) max_paths = cap_by_rays;
-    if (max_paths < 64) max_paths = 64;
-    uint32_t npix_chunk, spc;
-    if (sh.n_own_pix <= max_paths) {
-        npix_chunk = (uint32_t)sh.n_own_pix;
-        uint64_t k = max_paths / sh.n_own_pix;
-        spc = (uint32_t)(k < P.spp ? k : P.spp);
-    } else {
-        npix_chunk = (uint32_t)max_paths;
-        spc = 1;
-    }
-    const uint64_t cap_paths = (uint64_t)npix_chunk * spc;
     const uint32_t levels = P.bounces + 1;
-
-    if ((rc = s->w_counts.ensure(3 * (levels + 1)))) return rc;
-    for (int q = 0; q < 2; ++q) {
-        if ((rc = s->w_ray_o[q].ensure(cap_paths))) return rc;
-        if ((rc = s->w_ray_d[q].ensure(cap_paths))) return rc;
-    }
-    if ((rc = s->w_hit_id.ensure(cap_paths))) return rc;
-    if ((rc = s->w_hit_t.ensure(cap_paths))) return rc;
-    if ((rc = s->w_vP.ensure(cap_paths))) return rc;
-    if ((rc = s->w_vN.ensure(cap_paths))) return rc;
-    if ((rc = s->w_vS.ensure(cap_paths))) return rc;
-    if ((rc = s->w_rng.ensure(cap_paths))) return rc;
-    const bool persist = !hemi && nlL > 0 && s->dev.n_wnodes != 0u && s->opt_persist;   // k_shadow_p over the 8-wide occlusion BVH
+    const bool persist = !hemi && nlL > 0 && s->dev.n_wnodes != 0u && s->opt_persist;   // k_light + k_trace_p over the 8-wide occlusion BVH
     const bool in_wave = !persist && nlL > 0 && nlL <= 64 && (64 % nlL) == 0;
-    const uint64_t cap_slots = ((cap_paths + 63) / 64) * 64 * nlL;
-    if (persist && (rc = s->w_svis.ensure(cap_slots))) return rc;
-    if (persist && (rc = s->w_lray.ensure(2 * cap_slots))) return rc;
-    if (persist && (rc = s->w_blist.ensure(cap_slots))) return rc;
-    if (!persist && !in_wave && (rc = s->w_contrib.ensure(cap_paths * (nlL ? nlL : 1)))) return rc;
-    if ((rc = s->w_direct.ensure(cap_paths))) return rc;
-    if ((rc = s->w_stackA.ensure(cap_paths * (P.bounces ? P.bounces : 1)))) return rc;
-    if ((rc = s->w_stackB.ensure(cap_paths * (P.bounces ? P.bounces : 1)))) return rc;
-    if ((rc = s->w_radiance.ensure(cap_paths))) return rc;
-    if ((rc = s->w_accum.ensure(sh.n_own_pix))) return rc;
+    uint32_t npix_chunk = 0, spc = 0;
+    // Workspace for `max_paths` camera samples in flight (about 1.8 KB each at 32 light samples, depth 8).  Grow-only; when the
+    // device cannot hold it the pass size is halved until it does (results do not depend on the pass size).
+    for (uint64_t max_paths = s->opt_max_paths;; max_paths /= 2) {
+        if (max_paths > cap_by_rays) max_paths = cap_by_rays;
+        if (max_paths < 64) max_paths = 64;
+        if (sh.n_own_pix <= max_paths) {
+            npix_chunk = (uint32_t)sh.n_own_pix;
+            uint64_t k = max_paths / sh.n_own_pix;
+            spc = (uint32_t)(k < P.spp ? k : P.spp);
+        } else {
+            npix_chunk = (uint32_t)max_paths;
+            spc = 1;
+        }
+        const uint64_t cap_paths = (uint64_t)npix_chunk * spc;
+        const uint64_t cap_slots = ((cap_paths + 63) / 64) * 64 * nlL;
+        const uint64_t per_level = cap_paths * (P.bounces ? P.bounces : 1);
+        rc = s->w_counts.ensure(3 * (levels + 1));
+        for (int q = 0; q < 2 && !rc; ++q) {
+            rc = s->w_ray_o[q].ensure(cap_paths);
+            if (!rc) rc = s->w_ray_d[q].ensure(cap_paths);
+        }
+        if (!rc) rc = s->w_hit_id.ensure(cap_paths);
+        if (!rc) rc = s->w_hit_t.ensure(cap_paths);
+        if (!rc) rc = s->w_vP.ensure(cap_paths);
+        if (!rc) rc = s->w_vN.ensure(cap_paths);
+        if (!rc) rc = s->w_vS.ensure(cap_paths);
+        if (!rc) rc = s->w_rng.ensure(cap_paths);
+        if (!rc && persist) rc = s->w_svis.ensure(cap_slots);
+        if (!rc && persist) rc = s->w_lray.ensure(2 * cap_slots);
+        if (!rc && persist) rc = s->w_blist.ensure(cap_slots);
+        if (!rc && !persist && !in_wave) rc = s->w_contrib.ensure(cap_paths * (nlL ? nlL : 1));
+        if (!rc) rc = s->w_direct.ensure(cap_paths);
+        if (!rc) rc = s->w_stackA.ensure(per_level);
+        if (!rc) rc = s->w_stackB.ensure(per_level);
+        if (!rc) rc = s->w_radiance.ensure(cap_paths);
+        if (!rc) rc = s->w_accum.ensure(sh.n_own_pix);
+        if (!rc) break;
+        (void)hipGetLastError();   // clear the out-of-memory error
+        if (max_paths <= 65536) return rc;
+    }
     if ((rc = ensure_jump(s, nlL, stream))) return rc;
 
     PassCtx pc;

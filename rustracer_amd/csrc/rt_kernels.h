@@ -456,19 +456,22 @@ __device__ __forceinline__ bool wide_prim_step(const DevScene& sc, const BoxRay&
     if (!(rest & 0xFFu)) rest = 0u;
     const float4* tp = sc.wprims + 3 * (size_t)prim;
     const float4 A = tp[0], B = tp[1];
+    // blocked = own box passed (exact slab test) && primitive hit && 0 < t < max_dist, evaluated cheapest-first: most
+    // candidates fail the primitive test, and only the few that pass need the box test that makes them a candidate at all
     float t = 0.0f, tn;
     bool ok;
     if (__float_as_uint(A.w) == 0u) {
         const float4 C = tp[2];
         if (STATS) ts->tris++;
-        ok = slab(br, lo3(A.x, B.x, C.x), lo3(A.y, B.y, C.y), lo3(A.z, B.z, C.z), hi3(A.x, B.x, C.x), hi3(A.y, B.y, C.y), hi3(A.z, B.z, C.z), &tn) &&
-             hit_triangle(xyz(A), xyz(B), xyz(C), o, d, &t);
+        ok = hit_triangle(xyz(A), xyz(B), xyz(C), o, d, &t) && t > 0.0f && t < max_dist &&
+             slab(br, lo3(A.x, B.x, C.x), lo3(A.y, B.y, C.y), lo3(A.z, B.z, C.z), hi3(A.x, B.x, C.x), hi3(A.y, B.y, C.y), hi3(A.z, B.z, C.z), &tn);
     } else {
         if (STATS) ts->sphs++;
         const float r = B.x;
-        ok = slab(br, A.x - r, A.y - r, A.z - r, A.x + r, A.y + r, A.z + r, &tn) && hit_sphere(make_float4(A.x, A.y, A.z, r), o, d, &t);
+        ok = hit_sphere(make_float4(A.x, A.y, A.z, r), o, d, &t) && t > 0.0f && t < max_dist &&
+             slab(br, A.x - r, A.y - r, A.z - r, A.x + r, A.y + r, A.z + r, &tn);
     }
-    if (ok && t > 0.0f && t < max_dist) {
+    if (ok) {
         cur = 0u;
         return true;
     }
