@@ -33,6 +33,22 @@ def tile_index_map(width, height, tile_w, tile_h, shard, world):
     return idx.reshape(-1)
 
 
+_INDEX_CACHE = {}
+
+
+def _device_index(width, height, tile_w, tile_h, shard, world, device):
+    """The index map of one shard as device tensors (gather source with padding clamped to 0, padding mask, scatter
+    destinations, scatter sources), built once per frame geometry: the per-frame gather must not rebuild or re-upload them."""
+    key = (width, height, tile_w, tile_h, shard, world, str(device))
+    hit = _INDEX_CACHE.get(key)
+    if hit is None:
+        idx = torch.as_tensor(tile_index_map(width, height, tile_w, tile_h, shard, world), device=device)
+        valid = idx >= 0
+        hit = (idx.clamp(min=0), ~valid, idx[valid], torch.nonzero(valid).reshape(-1))
+        _INDEX_CACHE[key] = hit
+    return hit
+
+
 def pack_tiles(frame, index_map):
     """frame: [H*W, C] tensor -> compact [n_slots*tile_pixels, C] (padding slots zero)."""
     idx = torch.as_tensor(index_map, device=frame.device)
@@ -56,10 +72,16 @@ def gather_frame(frame, width, height, tile_w, tile_h, rank, world, group=None):
         return frame
     c = frame.shape[-1]
     flat = frame.reshape(-1, c)
-    mine = pack_tiles(flat, tile_index_map(width, height, tile_w, tile_h, rank, world)).contiguous()
-    parts = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(parts, mine, group=group)
+    src, pad, _, _ = _device_index(width, height, tile_w, tile_h, rank, world, frame.device)
+    mine = flat[src]
+    mine[pad] = 0
+    gathered = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+    if dist.get_backend(group) == "nccl":                                      # RCCL: one collective, w*h*C bytes in total
+        dist.all_gather_into_tensor(gathered, mine.contiguous(), group=group)
+    else:                                                                      # gloo (CPU tests) has no all_gather_into_tensor
+        dist.all_gather([gathered[r] for r in range(world)], mine.contiguous(), group=group)
     out = torch.zeros_like(flat)
     for r in range(world):
-        unpack_tiles(parts[r], tile_index_map(width, height, tile_w, tile_h, r, world), out)
+        _, _, dst, sel = _device_index(width, height, tile_w, tile_h, r, world, frame.device)
+        out[dst] = gathered[r][sel]
     return out.reshape(frame.shape)
