@@ -145,7 +145,7 @@ def main():
         torch.cuda.synchronize(dev)
         sc = scene.counters()
         scene.set_option("stats", 0)
-        ts = dict(zip(["node_steps", "node_lanes", "prim_steps", "prim_lanes", "refills", "refill_lanes"], sc["trace_steps"]))
+        ts = dict(zip(["node_steps", "node_lanes", "prim_steps", "prim_lanes", "refills", "refill_lanes", "box_miss"], sc["trace_steps"]))
         launches = cnt["launches_shadow"]
         avg_ms = cnt["kernel_ms_shadow"] / launches
         if ts["refill_lanes"] > 0:
@@ -159,6 +159,7 @@ def main():
             rays_per_launch = traced_frac * cnt["rays_shadow"] / launches
             kernel = "k_trace_p<false,8> (Scene::is_occluded: persistent any-hit traversal of the 8-wide occlusion BVH with lane refill)"
             per_ray = {"wide_nodes_80B": round(nodes_per_ray, 3), "prim_records_48B": round(prims_per_ray, 3), "ray_io_B": 56,
+                       "false_candidates_per_ray": round(ts["box_miss"] / ts["refill_lanes"], 3),
                        "traced_fraction_of_is_occluded_rays": round(traced_frac, 4),
                        "lanes_per_node_step": round(ts["node_lanes"] / max(ts["node_steps"], 1), 1),
                        "lanes_per_prim_step": round(ts["prim_lanes"] / max(ts["prim_steps"], 1), 1),

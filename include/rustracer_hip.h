@@ -78,7 +78,8 @@ typedef struct rt_counters {
     uint64_t launches_closest, launches_shadow;
     uint64_t shadow_wide;     /* 8-wide occlusion-BVH nodes (80 B) fetched by is_occluded rays ("stats" on) */
     double   kernel_ms_light; /* HIP-event time of the light-sampling kernel (Object::sample_l + the self test), timing enabled */
-    uint64_t trace_steps[6];  /* persistent traversal kernel, "stats" on: wave-wide node steps, lanes in them, primitive steps, lanes, refills, lanes */
+    uint64_t trace_steps[8];  /* persistent traversal kernel, "stats" on: wave-wide node steps, lanes in them, primitive steps, lanes, refills, lanes,
+                               * primitive records whose own box the ray misses (false candidates of the quantised tree), spare */
 } rt_counters;
 
 typedef struct rt_scene rt_scene;

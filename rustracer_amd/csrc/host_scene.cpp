@@ -465,6 +465,7 @@ class WideBuilder {
     WideBuilder(const HostScene& sc, const FlatBVH& bvh, WideBVH* out) : sc_(sc), bvh_(bvh), out_(out) {
         out_->nodes.clear(); out_->prims.clear(); out_->depth = 0; out_->ok = false;
         const uint32_t T = sc.n_tri(), S = sc.n_sph(), n = T + S;
+        out_->rec_of_obj.assign(n, 0xFFFFFFFFu);
         if (!n) return;
         blocker_.resize(n);
         for (uint32_t i = 0; i < T; ++i) blocker_[i] = scene_is_black(sc.mats[sc.tri_mat[i]].emittance);
@@ -573,6 +574,7 @@ class WideBuilder {
 
     void emit_prim(uint32_t obj) {
         const uint32_t T = sc_.n_tri();
+        out_->rec_of_obj[obj] = out_->n_prims();
         float r[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (obj < T) {
             const float* p = &sc_.tri_pos[9 * (size_t)obj];

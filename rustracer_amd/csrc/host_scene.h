@@ -50,6 +50,7 @@ struct FlatBVH {
 struct WideBVH {
     std::vector<uint32_t> nodes;
     std::vector<float> prims;
+    std::vector<uint32_t> rec_of_obj;   // primitive record of each object, 0xFFFFFFFF for the emissive ones (not in the tree)
     uint32_t depth = 0;     // nodes on the longest root-to-primitive chain
     bool ok = false;        // false: no blockers, or the scene is outside the quantiser's range -> binary traversal only
     uint32_t n_nodes() const { return (uint32_t)(nodes.size() / 20); }

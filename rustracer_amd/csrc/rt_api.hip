@@ -64,7 +64,7 @@ struct rt_scene {
 
     DevBuf<float4> d_nodes, d_tris, d_tri_nrm, d_sph, d_mats, d_wnodes, d_wprims;
     DevBuf<uint2> d_sph_aux;
-    DevBuf<uint32_t> d_lights, d_ovf;
+    DevBuf<uint32_t> d_lights, d_ovf, d_wrec;
     DevScene dev;
     uint64_t device_bytes = 0;
 
@@ -116,7 +116,7 @@ void prepare_host(rt_scene* s) {
     for (uint32_t i = 0; i < S; ++i)
         if (!scene_is_black(h.mats[h.sph_mat[i]].emittance)) s->lights.push_back(T + i);
     s->device_bytes = (uint64_t)s->bvh.n_inner() * 64 + (uint64_t)T * 96 + (uint64_t)S * 24 + (uint64_t)h.mats.size() * 32 + s->lights.size() * 4 +
-                      (uint64_t)s->wide.n_nodes() * 80 + (uint64_t)s->wide.n_prims() * 48;
+                      (uint64_t)s->wide.n_nodes() * 80 + (uint64_t)s->wide.n_prims() * 48 + (uint64_t)s->wide.rec_of_obj.size() * 4;
 }
 
 // Device half: flatten to the kernel layout and upload, on first use.
@@ -178,6 +178,8 @@ int upload_scene(rt_scene* s) {
         if ((rc = s->d_wprims.ensure(3 * (size_t)s->wide.n_prims()))) return rc;
         HIP_TRY(hipMemcpy(s->d_wnodes.p, s->wide.nodes.data(), s->wide.nodes.size() * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(s->d_wprims.p, s->wide.prims.data(), s->wide.prims.size() * 4, hipMemcpyHostToDevice));
+        if ((rc = s->d_wrec.ensure(s->wide.rec_of_obj.size()))) return rc;
+        HIP_TRY(hipMemcpy(s->d_wrec.p, s->wide.rec_of_obj.data(), s->wide.rec_of_obj.size() * 4, hipMemcpyHostToDevice));
     }
     if (ovf_rows && (rc = s->d_ovf.ensure((size_t)ovf_rows * s->grid_max * RT_BLOCK))) return rc;
     if (n_inner) {
@@ -212,7 +214,7 @@ int upload_scene(rt_scene* s) {
     }
     d.ovf = s->d_ovf.p; d.ovf_stride = s->grid_max * RT_BLOCK;
     d.inner_min = s->opt_inner_min; d.self_test = s->opt_self_test;
-    d.wnodes = s->d_wnodes.p; d.wprims = s->d_wprims.p;
+    d.wnodes = s->d_wnodes.p; d.wprims = s->d_wprims.p; d.wrec = s->d_wrec.p;
     d.n_wnodes = (s->wide.ok && s->opt_wide) ? s->wide.n_nodes() : 0u;
     d.refill_min = s->opt_refill_min; d.phase_bias = s->opt_phase_bias;
     if ((rc = s->w_stats.ensure(ST_COUNT))) return rc;
@@ -549,7 +551,7 @@ void rt_scene_destroy(rt_scene* s) {
     if (!s) return;
     if (s->uploaded) (void)hipDeviceSynchronize();
     s->d_nodes.release(); s->d_tris.release(); s->d_tri_nrm.release(); s->d_sph.release(); s->d_mats.release();
-    s->d_sph_aux.release(); s->d_lights.release(); s->d_ovf.release(); s->d_wnodes.release(); s->d_wprims.release();
+    s->d_sph_aux.release(); s->d_lights.release(); s->d_ovf.release(); s->d_wnodes.release(); s->d_wprims.release(); s->d_wrec.release();
     s->w_counts.release(); s->w_hit_id.release(); s->w_blist.release(); s->w_hit_t.release();
     for (int q = 0; q < 2; ++q) { s->w_ray_o[q].release(); s->w_ray_d[q].release(); }
     s->w_vP.release(); s->w_vN.release(); s->w_vS.release(); s->w_contrib.release(); s->w_direct.release(); s->w_stackA.release(); s->w_stackB.release();
@@ -675,7 +677,7 @@ int rt_get_counters(const rt_scene* cs, rt_counters* out) {
     if (out->rays_closest == 0 && s->launches[0] && s->samples) out->rays_closest = s->samples;   // primary cast: one ray per owned pixel
     out->closest_inner = st[ST_C_INNER]; out->closest_tris = st[ST_C_TRIS]; out->closest_sphs = st[ST_C_SPHS];
     out->shadow_inner = st[ST_S_INNER]; out->shadow_tris = st[ST_S_TRIS]; out->shadow_sphs = st[ST_S_SPHS]; out->shadow_wide = st[ST_S_WIDE];
-    for (int k = 0; k < 6; ++k) out->trace_steps[k] = st[ST_P_NODE_STEPS + k];
+    for (int k = 0; k < 8; ++k) out->trace_steps[k] = st[ST_P_NODE_STEPS + k];
     out->closest_hits_tri = st[ST_HITS_TRI]; out->closest_hits_sph = st[ST_HITS_SPH];
     double ms[4] = {0, 0, 0, 0};
     for (size_t i = 0; i < s->events_used; ++i) {

@@ -50,6 +50,7 @@ struct DevScene {
     uint32_t inner_min;      // traverse(): leaf tests start when fewer lanes than this are still at inner nodes
     const float4* wnodes;    // occlusion BVH (host_scene.h WideBVH): 5 x float4 per 8-wide node (80 B)
     const float4* wprims;    // 3 x float4 per blocker primitive record (48 B), in node order
+    const uint32_t* wrec;    // primitive record of each object in wprims (0xFFFFFFFF: emissive, not in the tree)
     uint32_t n_wnodes;       // 0: shadow rays take the binary tree
     uint32_t refill_min;     // k_trace_p: idle lanes that trigger a refill of the wave
     uint32_t phase_bias;     // k_trace_p: node step when 4 * lanes_at_nodes >= phase_bias * lanes_at_primitives
@@ -57,6 +58,7 @@ struct DevScene {
 
 struct TravStats {
     uint32_t inner, tris, sphs, wide;
+    uint32_t box_miss;   // k_trace_p: primitive records whose own (exact) box the ray misses: false candidates of the quantised tree
 };
 
 struct PassCtx {
@@ -95,7 +97,7 @@ struct PassCtx {
 
 // traversal work is counted per ray class: [ST_C_*] closest-hit rays, [ST_S_*] shadow (any-hit) rays
 enum { ST_RAYS_CLOSEST = 0, ST_RAYS_SHADOW, ST_C_INNER, ST_C_TRIS, ST_C_SPHS, ST_S_INNER, ST_S_TRIS, ST_S_SPHS, ST_HITS_TRI, ST_HITS_SPH, ST_S_WIDE,
-       ST_P_NODE_STEPS, ST_P_NODE_LANES, ST_P_PRIM_STEPS, ST_P_PRIM_LANES, ST_P_REFILLS, ST_P_REFILL_LANES, ST_COUNT };
+       ST_P_NODE_STEPS, ST_P_NODE_LANES, ST_P_PRIM_STEPS, ST_P_PRIM_LANES, ST_P_REFILLS, ST_P_REFILL_LANES, ST_P_BOX_MISS, ST_P_SPARE, ST_COUNT };
 
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ vec3 xyz(float4 v) { return mk(v.x, v.y, v.z); }
@@ -399,7 +401,7 @@ __device__ __forceinline__ bool wide_ray_ok(const BoxRay& br, vec3 o) {
 
 // One node of the 8-wide tree for this lane: `cur` is an inner group; on return it is the next group (0 = ray finished).
 template <bool STATS>
-__device__ __forceinline__ void wide_node_step(const DevScene& sc, const BoxRay& br, float lim, uint32_t& cur, Stack& st, TravStats* ts) {
+__device__ __forceinline__ void wide_node_step(const DevScene& sc, const BoxRay& br, float lim, uint32_t skip_rec, uint32_t& cur, Stack& st, TravStats* ts) {
     const uint32_t node = (cur >> 8) + (uint32_t)__ffs((int)(cur & 0xFFu)) - 1u;
     uint32_t rest = cur & (cur - 1u);
     if (!(rest & 0xFFu)) rest = 0u;
@@ -435,7 +437,12 @@ __device__ __forceinline__ void wide_node_step(const DevScene& sc, const BoxRay&
     }
     hm &= (1u << (meta >> 28)) - 1u;                       // slots in use
     const uint32_t k = (meta >> 24) & 0xFu;
-    const uint32_t ih = hm & ((1u << k) - 1u), ph = hm >> k;
+    const uint32_t ih = hm & ((1u << k) - 1u);
+    uint32_t ph = hm >> k;
+    // skip_rec: a record the caller has already tested for this ray (the object the ray starts on, k_light), else 0xFFFFFFFF.
+    // A ray that starts on a wall lies in the padded slab of that wall's own flat box, so it is a candidate of every such ray.
+    const uint32_t rel = skip_rec - __float_as_uint(n1.y);
+    if (rel < 8u) ph &= ~(1u << rel);
     uint32_t a = ph ? (RT_W_PRIM | (__float_as_uint(n1.y) << 8) | ph) : 0u;   // primitives first: a blocker ends the ray
     uint32_t b = ih ? ((__float_as_uint(n1.x) << 8) | ih) : 0u;
     uint32_t c = rest;
@@ -462,7 +469,10 @@ __device__ __forceinline__ bool wide_prim_step(const DevScene& sc, const BoxRay&
     bool ok;
     if (__float_as_uint(A.w) == 0u) {
         const float4 C = tp[2];
-        if (STATS) ts->tris++;
+        if (STATS) {
+            ts->tris++;
+            if (!slab(br, lo3(A.x, B.x, C.x), lo3(A.y, B.y, C.y), lo3(A.z, B.z, C.z), hi3(A.x, B.x, C.x), hi3(A.y, B.y, C.y), hi3(A.z, B.z, C.z), &tn)) ts->box_miss++;
+        }
         ok = hit_triangle(xyz(A), xyz(B), xyz(C), o, d, &t) && t > 0.0f && t < max_dist &&
              slab(br, lo3(A.x, B.x, C.x), lo3(A.y, B.y, C.y), lo3(A.z, B.z, C.z), hi3(A.x, B.x, C.x), hi3(A.y, B.y, C.y), hi3(A.z, B.z, C.z), &tn);
     } else {
@@ -497,7 +507,7 @@ __device__ __forceinline__ bool occluded(const DevScene& sc, bool have_ray, vec3
             const unsigned long long mi = __ballot(at_inner);
             if (!mi) break;
             if ((uint32_t)__popcll(mi) < inner_min && __ballot((cur & RT_W_PRIM) != 0u) != 0ull) break;
-            if (at_inner) wide_node_step<STATS>(sc, br, lim, cur, st, ts);
+            if (at_inner) wide_node_step<STATS>(sc, br, lim, 0xFFFFFFFFu, cur, st, ts);
         }
         if (cur & RT_W_PRIM)
             if (wide_prim_step<STATS>(sc, br, o, d, max_dist, cur, st, ts)) occ = true;
@@ -650,7 +660,7 @@ template <bool STATS>
 __global__ void __launch_bounds__(RT_BLOCK) k_primary(DevScene sc, rt_render_params P, uint32_t tiles_x, uint32_t n_own_pixels,
                                                      uint32_t* ids, float* ts_out, uint8_t* rgba, unsigned long long* stats) {
     RT_STACK_DECL;
-    TravStats tst = {0, 0, 0, 0};
+    TravStats tst = {0, 0, 0, 0, 0};
     const vec3 cam = mk(P.cam[0], P.cam[1], P.cam[2]);
     for (uint32_t op = blockIdx.x * RT_BLOCK + threadIdx.x; op < n_own_pixels; op += gridDim.x * RT_BLOCK) {
         uint32_t x, y;
@@ -700,7 +710,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_generate(PassCtx pc) {
 template <bool STATS>
 __global__ void __launch_bounds__(RT_BLOCK, 8) k_extend(DevScene sc, PassCtx pc, uint32_t level) {
     RT_STACK_DECL;
-    TravStats tst = {0, 0, 0, 0};
+    TravStats tst = {0, 0, 0, 0, 0};
     const uint32_t n = pc.counts[level];
     const float4* ro = pc.ray_o[level & 1];
     const float4* rd = pc.ray_d[level & 1];
@@ -777,7 +787,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_a(DevScene sc, PassCtx pc, u
 template <bool STATS, bool HEMI>
 __global__ void __launch_bounds__(RT_BLOCK, RT_SHADOW_WAVES) k_shadow(DevScene sc, PassCtx pc, uint32_t level) {
     RT_STACK_DECL;
-    TravStats tst = {0, 0, 0, 0};
+    TravStats tst = {0, 0, 0, 0, 0};
     const uint32_t n = pc.vcounts[level] * pc.nlL;
     const uint32_t L = pc.P.light_samples;
     uint32_t* red = s_stack;   // rows 0..3 of this wave's own (then empty) stack columns: red[k * RT_BLOCK + thread] = component k
@@ -876,7 +886,7 @@ __device__ __forceinline__ size_t ls_slot(uint32_t e, uint32_t j, uint32_t nlL) 
 }
 template <bool STATS, int WAVES>   // WAVES: waves per SIMD the register budget is sized for
 __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx pc, uint32_t level) {
-    TravStats tst = {0, 0, 0, 0};
+    TravStats tst = {0, 0, 0, 0, 0};
     const uint32_t n = pc.vcounts[level], n_round = (n + 63u) & ~63u;
     const uint32_t nlL = pc.nlL, L = pc.P.light_samples;
     uint32_t* flags = reinterpret_cast<uint32_t*>(pc.svis);
@@ -904,6 +914,8 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
                 self_is_sph = (sc.sph_aux[self_obj - sc.n_tri].y & RT_INFO_BLOCKER) != 0u;
             }
         }
+        // its record in the occlusion BVH: k_trace_p need not test it again for the rays that pass the test here
+        const float self_rec = __uint_as_float((self_is_tri || self_is_sph) ? sc.wrec[self_obj] : 0xFFFFFFFFu);
         const float bmnx = lo3(A.x, B.x, C.x), bmny = lo3(A.y, B.y, C.y), bmnz = lo3(A.z, B.z, C.z);
         const float bmxx = hi3(A.x, B.x, C.x), bmxy = hi3(A.y, B.y, C.y), bmxz = hi3(A.z, B.z, C.z);
         size_t sl = ls_slot(e, 0, nlL);                                        // slot of sample j: + 64 per sample
@@ -942,7 +954,7 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
             if (binary) pc.blist[atomicAdd(&pc.bcounts[level], 1u)] = (uint32_t)sl;
             if (!blocked) {
                 pc.lray[2 * sl] = make_float4(wi.x, wi.y, wi.z, d_s);
-                pc.lray[2 * sl + 1] = make_float4(br.ix, br.iy, br.iz, 0.0f);
+                pc.lray[2 * sl + 1] = make_float4(br.ix, br.iy, br.iz, self_rec);
             }
           }
         }
@@ -954,7 +966,7 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
 template <bool STATS>
 __global__ void __launch_bounds__(RT_BLOCK) k_binary(DevScene sc, PassCtx pc, uint32_t level) {
     RT_STACK_DECL;
-    TravStats tst = {0, 0, 0, 0};
+    TravStats tst = {0, 0, 0, 0, 0};
     const uint32_t n = pc.bcounts[level], nlL = pc.nlL;
     uint32_t* flags = reinterpret_cast<uint32_t*>(pc.svis);
     for (uint32_t i0 = blockIdx.x * RT_BLOCK + (threadIdx.x & ~63u); i0 < n; i0 += gridDim.x * RT_BLOCK) {
@@ -985,7 +997,7 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
     RT_STACK_DECL;
     __shared__ uint32_t s_pub[RT_BLOCK];
     uint32_t* pub = s_pub + (threadIdx.x & ~63u);
-    TravStats tst = {0, 0, 0, 0};
+    TravStats tst = {0, 0, 0, 0, 0};
     const uint32_t nlL = pc.nlL;
     const uint32_t n_slots = ((pc.vcounts[level] + 63u) >> 6) * 64u * nlL;      // < 2^31 (render_impl caps paths * nlL at 2^30)
     const uint32_t n_waves = gridDim.x * (RT_BLOCK / 64);
@@ -1004,7 +1016,7 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
     uint32_t w_steps[6] = {0, 0, 0, 0, 0, 0};   // STATS: wave steps and the lanes that took part (node, primitive, refill)
 
     // the ray this lane is tracing (cur != 0)
-    uint32_t cur = 0u, slot = 0u, cos_bits = 0u;
+    uint32_t cur = 0u, slot = 0u, cos_bits = 0u, skip_rec = 0xFFFFFFFFu;
     vec3 o = mk(0.0f, 0.0f, 0.0f), d = mk(0.0f, 0.0f, 1.0f);
     BoxRay br = make_box_ray(o, d);
     float max_dist = 0.0f, lim = 0.0f;
@@ -1050,6 +1062,7 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
                 o = xyz(P4); d = xyz(R4); max_dist = R4.w;
                 br.ox = o.x; br.oy = o.y; br.oz = o.z;
                 br.ix = I4.x; br.iy = I4.y; br.iz = I4.z;                     // make_box_ray(o, d), computed by k_light
+                skip_rec = __float_as_uint(I4.w);                              // the object the ray starts on: tested by k_light
                 br.sx = I4.x < 0.0f; br.sy = I4.y < 0.0f; br.sz = I4.z < 0.0f; // sign of the normalised direction (finite 1/d only: wide_ray_ok)
                 lim = prune_limit(max_dist);
                 if (wide_ray_ok(br, o)) {      // the others are k_binary's
@@ -1066,15 +1079,21 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
         const uint32_t n_node = (uint32_t)__popcll(__ballot(at_node)), n_prim = (uint32_t)__popcll(__ballot(at_prim));
         if (n_node != 0u && (n_prim == 0u || 4u * n_node >= phase_bias * n_prim)) {
             if (STATS) { w_steps[0]++; w_steps[1] += n_node; }
-            if (at_node) wide_node_step<STATS>(sc, br, lim, cur, st, &tst);
+            if (at_node) wide_node_step<STATS>(sc, br, lim, skip_rec, cur, st, &tst);
         } else {
             if (STATS) { w_steps[2]++; w_steps[3] += n_prim; }
             if (at_prim && wide_prim_step<STATS>(sc, br, o, d, max_dist, cur, st, &tst)) flags[2 * (size_t)slot] = cos_bits | 0x80000000u;
         }
     }
     flush_stats<STATS>(pc.stats, tst, ST_S_INNER);
-    if (STATS && lane == 0u)
-        for (int k = 0; k < 6; ++k) atomicAdd(&pc.stats[ST_P_NODE_STEPS + k], (unsigned long long)w_steps[k]);
+    if (STATS) {
+        uint32_t bm = tst.box_miss;
+        for (int off = 32; off > 0; off >>= 1) bm += __shfl_xor(bm, off);
+        if (lane == 0u) {
+            for (int k = 0; k < 6; ++k) atomicAdd(&pc.stats[ST_P_NODE_STEPS + k], (unsigned long long)w_steps[k]);
+            atomicAdd(&pc.stats[ST_P_BOX_MISS], (unsigned long long)bm);
+        }
+    }
 }
 
 // The rest of one_bounce_radiance_importance and global_illumination (src/raytracer.rs:282-326).
@@ -1195,7 +1214,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_resolve(PassCtx pc) {
 // Arbitrary rays (rt_intersect_rays / rt_occluded_rays).
 __global__ void __launch_bounds__(RT_BLOCK) k_rays_closest(DevScene sc, const float* org, const float* dir, uint32_t n, uint32_t* ids, float* ts_out) {
     RT_STACK_DECL;
-    TravStats tst = {0, 0, 0, 0};
+    TravStats tst = {0, 0, 0, 0, 0};
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
         uint32_t id;
         float t;
@@ -1206,7 +1225,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_rays_closest(DevScene sc, const fl
 }
 __global__ void __launch_bounds__(RT_BLOCK) k_rays_occluded(DevScene sc, const float* org, const float* dir, const float* maxd, uint32_t n, uint8_t* out) {
     RT_STACK_DECL;
-    TravStats tst = {0, 0, 0, 0};
+    TravStats tst = {0, 0, 0, 0, 0};
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
         const bool occ = occluded<false>(sc, true, mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]), mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), maxd[i], RT_MISS, st, &tst);
         out[i] = occ ? 1 : 0;
