@@ -85,7 +85,7 @@ struct rt_scene {
 
     bool opt_stats = false, opt_timing = false;
     uint64_t opt_max_paths = 1ull << 24;
-    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 24, opt_phase_bias = 4, opt_shadow_waves = 8, opt_light_waves = 5;
+    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 24, opt_phase_bias = 4, opt_shadow_waves = 8, opt_light_waves = 4;
     uint32_t grid_max = 2048;
 
     std::vector<EventPair> events;
@@ -424,7 +424,8 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
                         if (s->opt_stats) hipLaunchKernelGGL((k_light<true, 5>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
                         else if (s->opt_light_waves >= 8) hipLaunchKernelGGL((k_light<false, 8>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
                         else if (s->opt_light_waves >= 6) hipLaunchKernelGGL((k_light<false, 6>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
-                        else hipLaunchKernelGGL((k_light<false, 5>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                        else if (s->opt_light_waves >= 5) hipLaunchKernelGGL((k_light<false, 5>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                        else hipLaunchKernelGGL((k_light<false, 4>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
                         if (s->opt_stats) hipLaunchKernelGGL(k_binary<true>, dim3(64), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
                         else hipLaunchKernelGGL(k_binary<false>, dim3(64), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
                         end_timing(s, stream, ev);

@@ -400,14 +400,9 @@ __device__ __forceinline__ bool wide_ray_ok(const BoxRay& br, vec3 o) {
 }
 
 // One node of the 8-wide tree for this lane: `cur` is an inner group; on return it is the next group (0 = ray finished).
-template <bool STATS>
-__device__ __forceinline__ void wide_node_step(const DevScene& sc, const BoxRay& br, float lim, uint32_t skip_rec, uint32_t& cur, Stack& st, TravStats* ts) {
-    const uint32_t node = (cur >> 8) + (uint32_t)__ffs((int)(cur & 0xFFu)) - 1u;
-    uint32_t rest = cur & (cur - 1u);
-    if (!(rest & 0xFFu)) rest = 0u;
-    const float4* np = sc.wnodes + 5 * (size_t)node;
-    const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-    if (STATS) ts->wide++;
+// The padded single-precision test of the 8 child slots of one wide node (derivation: the comment above): bit i set =
+// the ray may pass the box of slot i.  n0 = (grid origin, meta), n2..n4 = the 48 plane bytes.
+__device__ __forceinline__ uint32_t wide_child_mask(const BoxRay& br, float lim, float4 n0, float4 n2, float4 n3, float4 n4) {
     const uint32_t meta = __float_as_uint(n0.w);
     const float sx = ldexpf(br.ix, (int)(meta & 0xFFu) - WIDE_EXP_BIAS);
     const float sy = ldexpf(br.iy, (int)((meta >> 8) & 0xFFu) - WIDE_EXP_BIAS);
@@ -435,16 +430,35 @@ __device__ __forceinline__ void wide_node_step(const DevScene& sc, const BoxRay&
         const float tf = fminf(fminf(tfx, tfy), fminf(tfz, lim));
         hm |= tn <= tf ? (1u << i) : 0u;
     }
-    hm &= (1u << (meta >> 28)) - 1u;                       // slots in use
+    return hm & ((1u << (meta >> 28)) - 1u);                // slots in use
+}
+
+// Group entries for the hit slots `hm` of a node (n0.w = meta, n1 = first inner child, first record): `a` primitives
+// (minus skip_rec, a record the caller has already tested for this ray, else RT_W_NO_REC), `b` inner nodes.
+#define RT_W_NO_REC 0x7FFFFFu
+__device__ __forceinline__ void wide_groups(uint32_t hm, uint32_t meta, uint32_t child_base, uint32_t prim_base, uint32_t skip_rec, uint32_t* a, uint32_t* b) {
     const uint32_t k = (meta >> 24) & 0xFu;
     const uint32_t ih = hm & ((1u << k) - 1u);
     uint32_t ph = hm >> k;
-    // skip_rec: a record the caller has already tested for this ray (the object the ray starts on, k_light), else 0xFFFFFFFF.
-    // A ray that starts on a wall lies in the padded slab of that wall's own flat box, so it is a candidate of every such ray.
-    const uint32_t rel = skip_rec - __float_as_uint(n1.y);
+    // A ray that starts on a wall lies in the padded slab of that wall's own flat box, so the object a ray starts on is a
+    // candidate of nearly every such ray; k_light has tested it.
+    const uint32_t rel = skip_rec - prim_base;
     if (rel < 8u) ph &= ~(1u << rel);
-    uint32_t a = ph ? (RT_W_PRIM | (__float_as_uint(n1.y) << 8) | ph) : 0u;   // primitives first: a blocker ends the ray
-    uint32_t b = ih ? ((__float_as_uint(n1.x) << 8) | ih) : 0u;
+    *a = ph ? (RT_W_PRIM | (prim_base << 8) | ph) : 0u;
+    *b = ih ? ((child_base << 8) | ih) : 0u;
+}
+
+template <bool STATS>
+__device__ __forceinline__ void wide_node_step(const DevScene& sc, const BoxRay& br, float lim, uint32_t skip_rec, uint32_t& cur, Stack& st, TravStats* ts) {
+    const uint32_t node = (cur >> 8) + (uint32_t)__ffs((int)(cur & 0xFFu)) - 1u;
+    uint32_t rest = cur & (cur - 1u);
+    if (!(rest & 0xFFu)) rest = 0u;
+    const float4* np = sc.wnodes + 5 * (size_t)node;
+    const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+    if (STATS) ts->wide++;
+    const uint32_t hm = wide_child_mask(br, lim, n0, n2, n3, n4);
+    uint32_t a, b;
+    wide_groups(hm, __float_as_uint(n0.w), __float_as_uint(n1.x), __float_as_uint(n1.y), skip_rec, &a, &b);   // primitives first: a blocker ends the ray
     uint32_t c = rest;
     if (!a) { a = b; b = 0u; }
     if (!a) { a = c; c = 0u; }
@@ -507,7 +521,7 @@ __device__ __forceinline__ bool occluded(const DevScene& sc, bool have_ray, vec3
             const unsigned long long mi = __ballot(at_inner);
             if (!mi) break;
             if ((uint32_t)__popcll(mi) < inner_min && __ballot((cur & RT_W_PRIM) != 0u) != 0ull) break;
-            if (at_inner) wide_node_step<STATS>(sc, br, lim, 0xFFFFFFFFu, cur, st, ts);
+            if (at_inner) wide_node_step<STATS>(sc, br, lim, RT_W_NO_REC, cur, st, ts);
         }
         if (cur & RT_W_PRIM)
             if (wide_prim_step<STATS>(sc, br, o, d, max_dist, cur, st, ts)) occ = true;
@@ -915,7 +929,9 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
             }
         }
         // its record in the occlusion BVH: k_trace_p need not test it again for the rays that pass the test here
-        const float self_rec = __uint_as_float((self_is_tri || self_is_sph) ? sc.wrec[self_obj] : 0xFFFFFFFFu);
+        const uint32_t self_rec = (self_is_tri || self_is_sph) ? sc.wrec[self_obj] : RT_W_NO_REC;
+        // the root of the occlusion BVH (every traced ray's first node): tested here, with every lane busy
+        const float4 r0 = sc.wnodes[0], r2 = sc.wnodes[2], r3 = sc.wnodes[3], r4 = sc.wnodes[4];
         const float bmnx = lo3(A.x, B.x, C.x), bmny = lo3(A.y, B.y, C.y), bmnz = lo3(A.z, B.z, C.z);
         const float bmxx = hi3(A.x, B.x, C.x), bmxy = hi3(A.y, B.y, C.y), bmxz = hi3(A.z, B.z, C.z);
         size_t sl = ls_slot(e, 0, nlL);                                        // slot of sample j: + 64 per sample
@@ -954,7 +970,12 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
             if (binary) pc.blist[atomicAdd(&pc.bcounts[level], 1u)] = (uint32_t)sl;
             if (!blocked) {
                 pc.lray[2 * sl] = make_float4(wi.x, wi.y, wi.z, d_s);
-                pc.lray[2 * sl + 1] = make_float4(br.ix, br.iy, br.iz, self_rec);
+                uint32_t root_hits = 0u;
+                if (!binary) {
+                    if (STATS) tst.wide++;
+                    root_hits = wide_child_mask(br, prune_limit(d_s), r0, r2, r3, r4);
+                }
+                pc.lray[2 * sl + 1] = make_float4(br.ix, br.iy, br.iz, __uint_as_float(self_rec | (root_hits << 23)));
             }
           }
         }
@@ -1016,7 +1037,8 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
     uint32_t w_steps[6] = {0, 0, 0, 0, 0, 0};   // STATS: wave steps and the lanes that took part (node, primitive, refill)
 
     // the ray this lane is tracing (cur != 0)
-    uint32_t cur = 0u, slot = 0u, cos_bits = 0u, skip_rec = 0xFFFFFFFFu;
+    const uint32_t root_meta = __float_as_uint(sc.wnodes[0].w), root_child = __float_as_uint(sc.wnodes[1].x), root_prim = __float_as_uint(sc.wnodes[1].y);
+    uint32_t cur = 0u, slot = 0u, cos_bits = 0u, skip_rec = RT_W_NO_REC;
     vec3 o = mk(0.0f, 0.0f, 0.0f), d = mk(0.0f, 0.0f, 1.0f);
     BoxRay br = make_box_ray(o, d);
     float max_dist = 0.0f, lim = 0.0f;
@@ -1062,13 +1084,16 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
                 o = xyz(P4); d = xyz(R4); max_dist = R4.w;
                 br.ox = o.x; br.oy = o.y; br.oz = o.z;
                 br.ix = I4.x; br.iy = I4.y; br.iz = I4.z;                     // make_box_ray(o, d), computed by k_light
-                skip_rec = __float_as_uint(I4.w);                              // the object the ray starts on: tested by k_light
+                skip_rec = __float_as_uint(I4.w) & RT_W_NO_REC;                // the object the ray starts on: tested by k_light
                 br.sx = I4.x < 0.0f; br.sy = I4.y < 0.0f; br.sz = I4.z < 0.0f; // sign of the normalised direction (finite 1/d only: wide_ray_ok)
                 lim = prune_limit(max_dist);
-                if (wide_ray_ok(br, o)) {      // the others are k_binary's
-                    cur = 1u;                  // inner group {node 0}
-                    st.sp = 0;
-                }
+                // k_light has tested the root node: the ray starts at the root's hit slots (none: nothing can block it; the rays
+                // that are k_binary's carry no hits)
+                uint32_t a, b;
+                wide_groups(__float_as_uint(I4.w) >> 23, root_meta, root_child, root_prim, skip_rec, &a, &b);
+                st.sp = 0;
+                if (a && b) st.push(b);
+                cur = a ? a : b;
             }
             __builtin_amdgcn_wave_barrier();
             continue;
