@@ -84,6 +84,7 @@ struct PassCtx {
     float4* direct;                  // per vertex: light-sample sum (in_wave)
     uint32_t in_wave;                // nlL divides 64: k_shadow sums a vertex's light samples inside the wave
     float2* svis;                    // per light-sample slot (ls_slot), k_light: (|wi.n|, sign bit set = dead / occluded, pdf)
+    unsigned long long* tmask;       // per row of 64 light-sample slots, k_light: the slots k_trace_p has to trace
     float4* lray;                    // per light-sample slot, k_light: rays still to trace, 2 x float4: (wi, distance to the light sample), (1/d of the box test, 0)
     uint32_t persist;                // light samples go through k_light + k_trace_p; k_shade_b sums pc.svis
     float4* stackA;                  // [level][slot] (direct rgb, cos)
@@ -903,14 +904,12 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
     TravStats tst = {0, 0, 0, 0, 0};
     const uint32_t n = pc.vcounts[level], n_round = (n + 63u) & ~63u;
     const uint32_t nlL = pc.nlL, L = pc.P.light_samples;
-    uint32_t* flags = reinterpret_cast<uint32_t*>(pc.svis);
-    for (uint32_t e = blockIdx.x * RT_BLOCK + threadIdx.x; e < n_round; e += gridDim.x * RT_BLOCK) {
-        float4 N4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (e < n) N4 = pc.vN[e];
-        if (__float_as_uint(N4.w) == 0u) {                       // padding of the last tile
-            for (uint32_t j = 0; j < nlL; ++j) flags[2 * ls_slot(e, j, nlL)] = 0x80000000u;
-            continue;
-        }
+    for (uint32_t e0 = blockIdx.x * RT_BLOCK + threadIdx.x; e0 < n_round; e0 += gridDim.x * RT_BLOCK) {
+        // every queued vertex is live (k_shade_a compacts); the lanes beyond n only pad the last tile of 64: they run along on
+        // vertex 0 so that the wave votes below see whole rows, and store nothing
+        const bool live = e0 < n;
+        const uint32_t e = live ? e0 : 0u;
+        const float4 N4 = pc.vN[e];
         const float4 P4 = pc.vP[e];
         const vec3 p = xyz(P4), nrm = xyz(N4);
         const uint64_t rng0 = pc.rng[__float_as_uint(pc.vS[e].x)];
@@ -934,7 +933,8 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
         const float4 r0 = sc.wnodes[0], r2 = sc.wnodes[2], r3 = sc.wnodes[3], r4 = sc.wnodes[4];
         const float bmnx = lo3(A.x, B.x, C.x), bmny = lo3(A.y, B.y, C.y), bmnz = lo3(A.z, B.z, C.z);
         const float bmxx = hi3(A.x, B.x, C.x), bmxy = hi3(A.y, B.y, C.y), bmxz = hi3(A.z, B.z, C.z);
-        size_t sl = ls_slot(e, 0, nlL);                                        // slot of sample j: + 64 per sample
+        size_t sl = ls_slot(e0, 0, nlL);                                       // slot of sample j: + 64 per sample
+        unsigned long long* row_mask = pc.tmask + (size_t)(e0 >> 6) * nlL;    // row of (this tile, sample j): + 1 per sample
         for (uint32_t g = 0, j = 0; g < pc.n_groups; ++g) {                    // for light in lights (raytracer.rs:266): per-light values stay in registers
           const uint32_t light = sc.lights[g];
           const float4 cr = sc.sph[light - sc.n_tri];
@@ -964,19 +964,24 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
                 }
                 blocked = ok && t > 0.0f && t < d_s;
             }
-            pc.svis[sl] = make_float2(__uint_as_float(__float_as_uint(cos_theta) | (blocked ? 0x80000000u : 0u)), pdf);
             // 0 * inf = NaN cases of the slab test, or far-away coordinates: k_binary settles these few on the binary tree, which
-            // has the crate's NaN behaviour; k_trace_p recognises them by their 1/d and skips them
-            if (binary) pc.blist[atomicAdd(&pc.bcounts[level], 1u)] = (uint32_t)sl;
-            if (!blocked) {
-                pc.lray[2 * sl] = make_float4(wi.x, wi.y, wi.z, d_s);
-                uint32_t root_hits = 0u;
-                if (!binary) {
-                    if (STATS) tst.wide++;
-                    root_hits = wide_child_mask(br, prune_limit(d_s), r0, r2, r3, r4);
-                }
-                pc.lray[2 * sl + 1] = make_float4(br.ix, br.iy, br.iz, __uint_as_float(self_rec | (root_hits << 23)));
+            // has the crate's NaN behaviour
+            uint32_t root_hits = 0u;
+            if (!blocked && !binary) {
+                if (STATS) tst.wide++;
+                root_hits = wide_child_mask(br, prune_limit(d_s), r0, r2, r3, r4);
             }
+            const bool trace = live && root_hits != 0u;      // no root slot hit: nothing can block the ray
+            if (live) {
+                pc.svis[sl] = make_float2(__uint_as_float(__float_as_uint(cos_theta) | (blocked ? 0x80000000u : 0u)), pdf);
+                if (binary) pc.blist[atomicAdd(&pc.bcounts[level], 1u)] = (uint32_t)sl;
+                if (trace || binary) {
+                    pc.lray[2 * sl] = make_float4(wi.x, wi.y, wi.z, d_s);
+                    pc.lray[2 * sl + 1] = make_float4(br.ix, br.iy, br.iz, __uint_as_float(self_rec | (root_hits << 23)));
+                }
+            }
+            const unsigned long long m = __ballot(trace);     // the whole wave is here: one row of 64 slots
+            if (__lane_id() == 0u) row_mask[j] = m;
           }
         }
     }
@@ -1031,8 +1036,8 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
     uint32_t tile = next / (64u * nlL), jrow = (next >> 6) % nlL;              // tile and light sample of the row at `next`
     const uint32_t refill_min = sc.refill_min, phase_bias = sc.phase_bias;
     uint32_t* flags = reinterpret_cast<uint32_t*>(pc.svis);
-    // flags of the row at `next`, loaded one refill ahead so that a refill waits for one memory round trip, not two
-    uint32_t f_next = next < n_slots ? flags[2 * (size_t)(next + lane)] : 0x80000000u;
+    // rays to trace of the row at `next` (k_light's vote), loaded one refill ahead
+    unsigned long long m_next = next < n_slots ? pc.tmask[next >> 6] : 0ull;
 
     uint32_t w_steps[6] = {0, 0, 0, 0, 0, 0};   // STATS: wave steps and the lanes that took part (node, primitive, refill)
 
@@ -1048,7 +1053,7 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
         const uint32_t n_idle = (uint32_t)__popcll(idle);
         if ((pend != 0ull || next < n_slots) && n_idle >= refill_min) {
             if (pend == 0ull) {                                  // next row of 64 slots: which rays are still to trace
-                pend = __ballot(!(f_next & 0x80000000u));
+                pend = m_next;
                 row_base = next;
                 row_tile = tile;
                 next += 64u;
@@ -1060,7 +1065,7 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
                     tile = next / (64u * nlL);
                     jrow = (next >> 6) % nlL;
                 }
-                f_next = next < n_slots ? flags[2 * (size_t)(next + lane)] : 0x80000000u;   // no wave but this one writes the flags of its rows
+                m_next = next < n_slots ? pc.tmask[next >> 6] : 0ull;
                 if (pend == 0ull) continue;
             }
             const uint32_t n_pend = (uint32_t)__popcll(pend);
@@ -1087,8 +1092,7 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
                 skip_rec = __float_as_uint(I4.w) & RT_W_NO_REC;                // the object the ray starts on: tested by k_light
                 br.sx = I4.x < 0.0f; br.sy = I4.y < 0.0f; br.sz = I4.z < 0.0f; // sign of the normalised direction (finite 1/d only: wide_ray_ok)
                 lim = prune_limit(max_dist);
-                // k_light has tested the root node: the ray starts at the root's hit slots (none: nothing can block it; the rays
-                // that are k_binary's carry no hits)
+                // k_light has tested the root node: the ray starts at the root's hit slots
                 uint32_t a, b;
                 wide_groups(__float_as_uint(I4.w) >> 23, root_meta, root_child, root_prim, skip_rec, &a, &b);
                 st.sp = 0;
