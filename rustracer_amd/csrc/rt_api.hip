@@ -64,7 +64,7 @@ struct rt_scene {
 
     DevBuf<float4> d_nodes, d_tris, d_tri_nrm, d_sph, d_mats, d_wnodes, d_wprims;
     DevBuf<uint2> d_sph_aux;
-    DevBuf<uint32_t> d_lights, d_ovf, d_wrec;
+    DevBuf<uint32_t> d_lights, d_ovf, d_wrec, d_hot;
     DevScene dev;
     uint64_t device_bytes = 0;
 
@@ -86,7 +86,7 @@ struct rt_scene {
 
     bool opt_stats = false, opt_timing = false;
     uint64_t opt_max_paths = 1ull << 24;
-    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 24, opt_phase_bias = 4, opt_shadow_waves = 8, opt_light_waves = 4;
+    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 24, opt_phase_bias = 4, opt_shadow_waves = 8, opt_light_waves = 4, opt_hot = 1;
     uint32_t grid_max = 2048;
 
     std::vector<EventPair> events;
@@ -216,6 +216,46 @@ int upload_scene(rt_scene* s) {
     d.ovf = s->d_ovf.p; d.ovf_stride = s->grid_max * RT_BLOCK;
     d.inner_min = s->opt_inner_min; d.self_test = s->opt_self_test;
     d.wnodes = s->d_wnodes.p; d.wprims = s->d_wprims.p; d.wrec = s->d_wrec.p;
+    {
+        // Occluder cache of k_light: per light, the RT_HOT largest non-emissive objects whose box overlaps the light's box (a light
+        // recessed into or poking through a wall has most of its samples blocked by that wall).  A choice of test order only.
+        std::vector<uint32_t> hot(RT_HOT * (s->lights.empty() ? 1 : s->lights.size()), RT_W_NO_REC);
+        if (s->wide.ok && s->opt_hot) {
+            for (size_t li = 0; li < s->lights.size(); ++li) {
+                if (s->lights[li] < T) continue;   // triangle lights are rejected before any sampling
+                const float* c = &h.sph[4 * (size_t)(s->lights[li] - T)];
+                float best_area[RT_HOT];
+                for (int k = 0; k < RT_HOT; ++k) best_area[k] = -1.0f;
+                for (uint32_t r = 0; r < s->wide.n_prims(); ++r) {
+                    const float* q = &s->wide.prims[12 * (size_t)r];
+                    float mn[3], mx[3];
+                    if (float_to_bits(q[3]) == 0u) {
+                        for (int a = 0; a < 3; ++a) {
+                            mn[a] = q[a] < q[4 + a] ? (q[a] < q[8 + a] ? q[a] : q[8 + a]) : (q[4 + a] < q[8 + a] ? q[4 + a] : q[8 + a]);
+                            mx[a] = q[a] > q[4 + a] ? (q[a] > q[8 + a] ? q[a] : q[8 + a]) : (q[4 + a] > q[8 + a] ? q[4 + a] : q[8 + a]);
+                        }
+                    } else {
+                        for (int a = 0; a < 3; ++a) { mn[a] = q[a] - q[4]; mx[a] = q[a] + q[4]; }
+                    }
+                    bool overlap = true;
+                    for (int a = 0; a < 3; ++a) overlap = overlap && mn[a] <= c[a] + c[3] && mx[a] >= c[a] - c[3];
+                    if (!overlap) continue;
+                    const float sx = mx[0] - mn[0], sy = mx[1] - mn[1], sz = mx[2] - mn[2];
+                    float area = sx * sy + sx * sz + sy * sz;
+                    uint32_t rec = r;
+                    for (int k = 0; k < RT_HOT; ++k)   // insertion into the descending top list
+                        if (area > best_area[k]) {
+                            const float ta = best_area[k]; const uint32_t tr = hot[RT_HOT * li + k];
+                            best_area[k] = area; hot[RT_HOT * li + k] = rec;
+                            area = ta; rec = tr;
+                        }
+                }
+            }
+        }
+        if ((rc = s->d_hot.ensure(hot.size()))) return rc;
+        HIP_TRY(hipMemcpy(s->d_hot.p, hot.data(), hot.size() * 4, hipMemcpyHostToDevice));
+        d.hot = s->d_hot.p;
+    }
     d.n_wnodes = (s->wide.ok && s->opt_wide) ? s->wide.n_nodes() : 0u;
     d.refill_min = s->opt_refill_min; d.phase_bias = s->opt_phase_bias;
     if ((rc = s->w_stats.ensure(ST_COUNT))) return rc;
@@ -554,7 +594,7 @@ void rt_scene_destroy(rt_scene* s) {
     if (!s) return;
     if (s->uploaded) (void)hipDeviceSynchronize();
     s->d_nodes.release(); s->d_tris.release(); s->d_tri_nrm.release(); s->d_sph.release(); s->d_mats.release();
-    s->d_sph_aux.release(); s->d_lights.release(); s->d_ovf.release(); s->d_wnodes.release(); s->d_wprims.release(); s->d_wrec.release();
+    s->d_sph_aux.release(); s->d_lights.release(); s->d_ovf.release(); s->d_wnodes.release(); s->d_wprims.release(); s->d_wrec.release(); s->d_hot.release();
     s->w_counts.release(); s->w_hit_id.release(); s->w_blist.release(); s->w_hit_t.release();
     for (int q = 0; q < 2; ++q) { s->w_ray_o[q].release(); s->w_ray_d[q].release(); }
     s->w_vP.release(); s->w_vN.release(); s->w_vS.release(); s->w_contrib.release(); s->w_direct.release(); s->w_stackA.release(); s->w_stackB.release();
@@ -701,9 +741,11 @@ int rt_set_option(rt_scene* s, const char* name, uint64_t value) {
     else if (n == "self_test") { s->opt_self_test = value ? 1 : 0; s->dev.self_test = s->opt_self_test; }
     else if (n == "wide") { s->opt_wide = value ? 1 : 0; s->dev.n_wnodes = (s->wide.ok && s->opt_wide) ? s->wide.n_nodes() : 0u; }
     else if (n == "persist") s->opt_persist = value ? 1 : 0;
+    else if (n == "hot") { if (s->uploaded) return fail(RT_ERR_INVALID, "option 'hot' must be set before the first render"); s->opt_hot = value ? 1 : 0; }
     else if (n == "shadow_waves") s->opt_shadow_waves = (uint32_t)value;
     else if (n == "light_waves") s->opt_light_waves = (uint32_t)value;
     else if (n == "persist") s->opt_persist = value ? 1 : 0;
+    else if (n == "hot") { if (s->uploaded) return fail(RT_ERR_INVALID, "option 'hot' must be set before the first render"); s->opt_hot = value ? 1 : 0; }
     else if (n == "shadow_waves") s->opt_shadow_waves = (uint32_t)value;
     else if (n == "light_waves") s->opt_light_waves = (uint32_t)value;
     else if (n == "refill_min") { s->opt_refill_min = value > 64 ? 64 : (value < 1 ? 1 : (uint32_t)value); s->dev.refill_min = s->opt_refill_min; }

@@ -33,6 +33,7 @@ namespace rt {
 #define RT_PI 3.14159265358979323846f
 #define RT_ROULETTE 0.7f         // src/raytracer.rs:11
 #define RT_INFO_BLOCKER 0x80000000u
+#define RT_HOT 2                // occluders tested in k_light before any traversal, per light
 #define RT_CHUNK 512u           // persistent kernels: consecutive queue entries a wave takes at a time
 
 struct DevScene {
@@ -51,6 +52,7 @@ struct DevScene {
     const float4* wnodes;    // occlusion BVH (host_scene.h WideBVH): 5 x float4 per 8-wide node (80 B)
     const float4* wprims;    // 3 x float4 per blocker primitive record (48 B), in node order
     const uint32_t* wrec;    // primitive record of each object in wprims (0xFFFFFFFF: emissive, not in the tree)
+    const uint32_t* hot;     // per light, RT_HOT records of the occlusion BVH that k_light tests first (RT_W_NO_REC = none): see k_light
     uint32_t n_wnodes;       // 0: shadow rays take the binary tree
     uint32_t refill_min;     // k_trace_p: idle lanes that trigger a refill of the wave
     uint32_t phase_bias;     // k_trace_p: node step when 4 * lanes_at_nodes >= phase_bias * lanes_at_primitives
@@ -929,8 +931,6 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
         }
         // its record in the occlusion BVH: k_trace_p need not test it again for the rays that pass the test here
         const uint32_t self_rec = (self_is_tri || self_is_sph) ? sc.wrec[self_obj] : RT_W_NO_REC;
-        // the root of the occlusion BVH (every traced ray's first node): tested here, with every lane busy
-        const float4 r0 = sc.wnodes[0], r2 = sc.wnodes[2], r3 = sc.wnodes[3], r4 = sc.wnodes[4];
         const float bmnx = lo3(A.x, B.x, C.x), bmny = lo3(A.y, B.y, C.y), bmnz = lo3(A.z, B.z, C.z);
         const float bmxx = hi3(A.x, B.x, C.x), bmxy = hi3(A.y, B.y, C.y), bmxz = hi3(A.z, B.z, C.z);
         size_t sl = ls_slot(e0, 0, nlL);                                       // slot of sample j: + 64 per sample
@@ -939,6 +939,12 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
           const uint32_t light = sc.lights[g];
           const float4 cr = sc.sph[light - sc.n_tri];
           const float d_c = length3(sub(xyz(cr), p));
+          // Occluder cache: is_occluded is "some non-emissive object blocks", whichever is found first, so the large occluders next
+          // to this light (chosen at scene build: a ceiling the lamp pokes through blocks 4 of 5 samples of the Cornell lamp) are
+          // tested here, by every lane and from registers, before any ray is queued for traversal.  Same exact tests as at a leaf.
+          uint32_t hot_rec[RT_HOT];
+#pragma unroll
+          for (int h = 0; h < RT_HOT; ++h) hot_rec[h] = sc.hot[RT_HOT * g + h];
           for (uint32_t ls = 0; ls < L; ++ls, ++j, sl += 64) {                 // for _ in 0..light_samples (raytracer.rs:269)
             const ulonglong2 jm = pc.jump[j];
             uint64_t rng = jm.x * rng0 + jm.y;
@@ -964,12 +970,39 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
                 }
                 blocked = ok && t > 0.0f && t < d_s;
             }
+#pragma unroll
+            for (int h = 0; h < RT_HOT; ++h) {
+                if (hot_rec[h] != RT_W_NO_REC && hot_rec[h] != self_rec && !binary && !blocked) {      // (uniform but for the last three)
+                    // the record is fetched here, through the scalar cache, every sample: kept in registers across the loop
+                    // it costs more registers than this kernel has
+                    const float4* hp = sc.wprims + 3 * (size_t)hot_rec[h];
+                    asm volatile("" : "+s"(hp));
+                    const float4 hA = hp[0], hB = hp[1], hC = hp[2];
+                    float t = 0.0f, tn;
+                    bool ok;
+                    if (__float_as_uint(hA.w) == 0u) {
+                        if (STATS) tst.tris++;
+                        ok = hit_triangle(xyz(hA), xyz(hB), xyz(hC), p, wi, &t) && t > 0.0f && t < d_s &&
+                             slab(br, lo3(hA.x, hB.x, hC.x), lo3(hA.y, hB.y, hC.y), lo3(hA.z, hB.z, hC.z), hi3(hA.x, hB.x, hC.x), hi3(hA.y, hB.y, hC.y),
+                                  hi3(hA.z, hB.z, hC.z), &tn);
+                    } else {
+                        if (STATS) tst.sphs++;
+                        const float r = hB.x;
+                        ok = hit_sphere(make_float4(hA.x, hA.y, hA.z, r), p, wi, &t) && t > 0.0f && t < d_s &&
+                             slab(br, hA.x - r, hA.y - r, hA.z - r, hA.x + r, hA.y + r, hA.z + r, &tn);
+                    }
+                    blocked = ok;
+                }
+            }
             // 0 * inf = NaN cases of the slab test, or far-away coordinates: k_binary settles these few on the binary tree, which
             // has the crate's NaN behaviour
             uint32_t root_hits = 0u;
             if (!blocked && !binary) {
+                // the root of the occlusion BVH (every traced ray's first node): tested here, with every lane busy
+                const float4* rp = sc.wnodes;
+                asm volatile("" : "+s"(rp));
                 if (STATS) tst.wide++;
-                root_hits = wide_child_mask(br, prune_limit(d_s), r0, r2, r3, r4);
+                root_hits = wide_child_mask(br, prune_limit(d_s), rp[0], rp[2], rp[3], rp[4]);
             }
             const bool trace = live && root_hits != 0u;      // no root slot hit: nothing can block the ray
             if (live) {
