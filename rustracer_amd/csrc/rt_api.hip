@@ -86,7 +86,7 @@ struct rt_scene {
 
     bool opt_stats = false, opt_timing = false;
     uint64_t opt_max_paths = 1ull << 24;
-    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 24, opt_phase_bias = 4, opt_shadow_waves = 8, opt_light_waves = 4, opt_hot = 1;
+    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 16, opt_phase_bias = 4, opt_shadow_waves = 8, opt_light_waves = 4, opt_hot = 1, opt_root_in_light = 0;
     uint32_t grid_max = 2048;
 
     std::vector<EventPair> events;
@@ -215,7 +215,7 @@ int upload_scene(rt_scene* s) {
     }
     d.ovf = s->d_ovf.p; d.ovf_stride = s->grid_max * RT_BLOCK;
     d.inner_min = s->opt_inner_min; d.self_test = s->opt_self_test;
-    d.wnodes = s->d_wnodes.p; d.wprims = s->d_wprims.p; d.wrec = s->d_wrec.p;
+    d.wnodes = s->d_wnodes.p; d.wprims = s->d_wprims.p; d.wrec = s->d_wrec.p; d.root_in_light = s->opt_root_in_light;
     {
         // Occluder cache of k_light: per light, the RT_HOT largest non-emissive objects whose box overlaps the light's box (a light
         // recessed into or poking through a wall has most of its samples blocked by that wall).  A choice of test order only.
@@ -463,11 +463,14 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
                     const uint32_t gs = grid_for(s, (uint64_t)pc.npaths * nlL);
                     begin_timing(s, stream, hemi ? 0 : (persist ? 3 : 1), &ev);
                     if (persist) {
-                        if (s->opt_stats) hipLaunchKernelGGL((k_light<true, 5>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
-                        else if (s->opt_light_waves >= 8) hipLaunchKernelGGL((k_light<false, 8>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
-                        else if (s->opt_light_waves >= 6) hipLaunchKernelGGL((k_light<false, 6>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
-                        else if (s->opt_light_waves >= 5) hipLaunchKernelGGL((k_light<false, 5>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
-                        else hipLaunchKernelGGL((k_light<false, 4>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                        const bool root = s->opt_root_in_light != 0;
+                        if (s->opt_stats) { if (root) hipLaunchKernelGGL((k_light<true, 4, true>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                                            else hipLaunchKernelGGL((k_light<true, 4, false>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level); }
+                        else if (root) hipLaunchKernelGGL((k_light<false, 4, true>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                        else if (s->opt_light_waves >= 8) hipLaunchKernelGGL((k_light<false, 8, false>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                        else if (s->opt_light_waves >= 6) hipLaunchKernelGGL((k_light<false, 6, false>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                        else if (s->opt_light_waves >= 5) hipLaunchKernelGGL((k_light<false, 5, false>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                        else hipLaunchKernelGGL((k_light<false, 4, false>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
                         if (s->opt_stats) hipLaunchKernelGGL(k_binary<true>, dim3(64), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
                         else hipLaunchKernelGGL(k_binary<false>, dim3(64), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
                         end_timing(s, stream, ev);
@@ -741,10 +744,7 @@ int rt_set_option(rt_scene* s, const char* name, uint64_t value) {
     else if (n == "self_test") { s->opt_self_test = value ? 1 : 0; s->dev.self_test = s->opt_self_test; }
     else if (n == "wide") { s->opt_wide = value ? 1 : 0; s->dev.n_wnodes = (s->wide.ok && s->opt_wide) ? s->wide.n_nodes() : 0u; }
     else if (n == "persist") s->opt_persist = value ? 1 : 0;
-    else if (n == "hot") { if (s->uploaded) return fail(RT_ERR_INVALID, "option 'hot' must be set before the first render"); s->opt_hot = value ? 1 : 0; }
-    else if (n == "shadow_waves") s->opt_shadow_waves = (uint32_t)value;
-    else if (n == "light_waves") s->opt_light_waves = (uint32_t)value;
-    else if (n == "persist") s->opt_persist = value ? 1 : 0;
+    else if (n == "root_in_light") { s->opt_root_in_light = value ? 1 : 0; s->dev.root_in_light = s->opt_root_in_light; }
     else if (n == "hot") { if (s->uploaded) return fail(RT_ERR_INVALID, "option 'hot' must be set before the first render"); s->opt_hot = value ? 1 : 0; }
     else if (n == "shadow_waves") s->opt_shadow_waves = (uint32_t)value;
     else if (n == "light_waves") s->opt_light_waves = (uint32_t)value;

@@ -52,6 +52,7 @@ struct DevScene {
     const float4* wnodes;    // occlusion BVH (host_scene.h WideBVH): 5 x float4 per 8-wide node (80 B)
     const float4* wprims;    // 3 x float4 per blocker primitive record (48 B), in node order
     const uint32_t* wrec;    // primitive record of each object in wprims (0xFFFFFFFF: emissive, not in the tree)
+    uint32_t root_in_light;  // k_light tests the root node of the occlusion BVH (else k_trace_p starts there)
     const uint32_t* hot;     // per light, RT_HOT records of the occlusion BVH that k_light tests first (RT_W_NO_REC = none): see k_light
     uint32_t n_wnodes;       // 0: shadow rays take the binary tree
     uint32_t refill_min;     // k_trace_p: idle lanes that trigger a refill of the wave
@@ -901,7 +902,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SHADOW_WAVES) k_shadow(DevScene s
 __device__ __forceinline__ size_t ls_slot(uint32_t e, uint32_t j, uint32_t nlL) {
     return (size_t)(e >> 6) * (64u * (size_t)nlL) + (size_t)j * 64u + (e & 63u);
 }
-template <bool STATS, int WAVES>   // WAVES: waves per SIMD the register budget is sized for
+template <bool STATS, int WAVES, bool ROOT>   // WAVES: waves per SIMD the register budget is sized for; ROOT: test the BVH root here
 __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx pc, uint32_t level) {
     TravStats tst = {0, 0, 0, 0, 0};
     const uint32_t n = pc.vcounts[level], n_round = (n + 63u) & ~63u;
@@ -997,7 +998,8 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
             // 0 * inf = NaN cases of the slab test, or far-away coordinates: k_binary settles these few on the binary tree, which
             // has the crate's NaN behaviour
             uint32_t root_hits = 0u;
-            if (!blocked && !binary) {
+            if (!ROOT && !blocked && !binary) root_hits = 0x100u;    // k_trace_p starts at the root
+            if (ROOT && !blocked && !binary) {
                 // the root of the occlusion BVH (every traced ray's first node): tested here, with every lane busy
                 const float4* rp = sc.wnodes;
                 asm volatile("" : "+s"(rp));
@@ -1131,6 +1133,7 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
                 st.sp = 0;
                 if (a && b) st.push(b);
                 cur = a ? a : b;
+                if (!sc.root_in_light) cur = 1u;      // inner group {node 0}
             }
             __builtin_amdgcn_wave_barrier();
             continue;
