@@ -135,7 +135,10 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- roofline of the dominant kernel (k_trace_p: Scene::is_occluded for the light-sample rays that survive k_light) ----
+    # ---- roofline of the dominant kernel ----
+    # Three kernels carry the frame: k_light (Object::sample_l + the occluder-cache tests, one thread per path vertex looping over the
+    # light samples), k_trace_p (Scene::is_occluded for the survivors) and k_extend (Scene::intersect).  Each gets its algorithmic
+    # bytes per launch over its HIP-event launch time; `roofline` is the one with the largest share of the frame.
     roofline = None
     if a.stats_spp > 0 and cnt["launches_shadow"] > 0:
         sp = params.copy()
@@ -147,48 +150,80 @@ def main():
         scene.set_option("stats", 0)
         ts = dict(zip(["node_steps", "node_lanes", "prim_steps", "prim_lanes", "refills", "refill_lanes", "box_miss"], sc["trace_steps"]))
         launches = cnt["launches_shadow"]
-        avg_ms = cnt["kernel_ms_shadow"] / launches
+        n_shadow = max(sc["rays_shadow"], 1)
+        nlL = a.light_samples * len(scene.light_indexes())
+        kernels = {}
         if ts["refill_lanes"] > 0:
-            # Algorithmic bytes of one traced ray: 80 B per 8-wide node visited, 48 B per primitive record tested, and
-            # 56 B of ray I/O (32 B ray record + 16 B vertex position + 4 B flag read + 4 B flag write-back, the last counted for every ray).
-            # k_light settles the other is_occluded rays (test of the object the ray starts on) before this kernel; they are not counted here.
-            traced_frac = ts["refill_lanes"] / max(sc["rays_shadow"], 1)
+            # k_trace_p, per traced ray: 80 B per 8-wide node visited, 48 B per primitive record tested, 56 B of ray I/O
+            # (32 B ray record + 16 B vertex position + 4 B flag read + 4 B flag write-back).  The rays k_light settles are not counted.
+            traced_frac = ts["refill_lanes"] / n_shadow
             nodes_per_ray = ts["node_lanes"] / ts["refill_lanes"]
             prims_per_ray = ts["prim_lanes"] / ts["refill_lanes"]
-            bytes_per_ray = 80.0 * nodes_per_ray + 48.0 * prims_per_ray + 56.0
-            rays_per_launch = traced_frac * cnt["rays_shadow"] / launches
-            kernel = "k_trace_p<false,8> (Scene::is_occluded: persistent any-hit traversal of the 8-wide occlusion BVH with lane refill)"
-            per_ray = {"wide_nodes_80B": round(nodes_per_ray, 3), "prim_records_48B": round(prims_per_ray, 3), "ray_io_B": 56,
-                       "false_candidates_per_ray": round(ts["box_miss"] / ts["refill_lanes"], 3),
-                       "traced_fraction_of_is_occluded_rays": round(traced_frac, 4),
-                       "lanes_per_node_step": round(ts["node_lanes"] / max(ts["node_steps"], 1), 1),
-                       "lanes_per_prim_step": round(ts["prim_lanes"] / max(ts["prim_steps"], 1), 1),
-                       "lanes_per_refill": round(ts["refill_lanes"] / max(ts["refills"], 1), 1)}
+            b_trace = 80.0 * nodes_per_ray + 48.0 * prims_per_ray + 56.0
+            kernels["k_trace_p"] = {
+                "what": "Scene::is_occluded: persistent any-hit traversal of the 8-wide occlusion BVH with lane refill",
+                "unit": "traced ray", "bytes_per_unit": round(b_trace, 1), "units_per_launch": round(traced_frac * cnt["rays_shadow"] / launches, 1),
+                "launches_per_step": int(launches), "ms_per_step": round(cnt["kernel_ms_shadow"], 2),
+                "per_unit": {"wide_nodes_80B": round(nodes_per_ray, 3), "prim_records_48B": round(prims_per_ray, 3), "ray_io_B": 56,
+                             "false_candidates": round(ts["box_miss"] / ts["refill_lanes"], 3),
+                             "traced_fraction_of_is_occluded_rays": round(traced_frac, 4),
+                             "lanes_per_node_step": round(ts["node_lanes"] / max(ts["node_steps"], 1), 1),
+                             "lanes_per_prim_step": round(ts["prim_lanes"] / max(ts["prim_steps"], 1), 1),
+                             "lanes_per_refill": round(ts["refill_lanes"] / max(ts["refills"], 1), 1)}}
+            # k_light, per light sample: the vertex record (position 16 B, normal 16 B, path slot 8 B, RNG state 8 B) is read once per
+            # vertex and serves nlL samples; every sample writes its (|cos|, pdf) pair (8 B) and 1/64 of a row mask (8 B); a ray left
+            # to trace also writes its 32-B record.
+            b_light = 48.0 / max(nlL, 1) + 8.0 + 8.0 / 64.0 + 32.0 * traced_frac
+            kernels["k_light"] = {
+                "what": "Object::sample_l for every (vertex, light sample) + the test of the object the ray starts on + the per-light occluder cache",
+                "unit": "light sample", "bytes_per_unit": round(b_light, 2), "units_per_launch": round(cnt["rays_shadow"] / launches, 1),
+                "launches_per_step": int(launches), "ms_per_step": round(cnt["kernel_ms_light"], 2)}
         else:
             # binary-tree kernel (option wide=0 / persist=0, or a scene outside the 8-wide tree's range): SURVEY.md §8(d) formula
-            bytes_per_ray = (80.0 * sc["shadow_wide"] + 64.0 * sc["shadow_inner"] + 48.0 * sc["shadow_tris"] + 16.0 * sc["shadow_sphs"]) \
-                / max(sc["rays_shadow"], 1) + 48.0
-            rays_per_launch = cnt["rays_shadow"] / launches
-            kernel = "k_shadow<false,false> (Scene::is_occluded, one thread per light sample)"
-            per_ray = {"wide_nodes_80B": round(sc["shadow_wide"] / max(sc["rays_shadow"], 1), 3), "binary_nodes_64B": round(sc["shadow_inner"] / max(sc["rays_shadow"], 1), 3),
-                       "tri_48B": round(sc["shadow_tris"] / max(sc["rays_shadow"], 1), 3)}
-        achieved = bytes_per_ray * rays_per_launch / (avg_ms * 1e-3) / 1e9
-        bytes_per_closest_ray = (64.0 * sc["closest_inner"] + 48.0 * sc["closest_tris"] + 16.0 * sc["closest_sphs"]) / max(sc["rays_closest"], 1) + 48.0 \
-            + (80.0 * sc["closest_hits_tri"] + 32.0 * sc["closest_hits_sph"]) / max(sc["rays_closest"], 1)
-        traffic, traffic_src = pmc_traffic(a, "k_trace_p")
+            b_shadow = (80.0 * sc["shadow_wide"] + 64.0 * sc["shadow_inner"] + 48.0 * sc["shadow_tris"] + 16.0 * sc["shadow_sphs"]) / n_shadow + 48.0
+            kernels["k_shadow"] = {
+                "what": "Scene::is_occluded, one thread per light sample (sampling and traversal in one kernel)",
+                "unit": "is_occluded ray", "bytes_per_unit": round(b_shadow, 1), "units_per_launch": round(cnt["rays_shadow"] / launches, 1),
+                "launches_per_step": int(launches), "ms_per_step": round(cnt["kernel_ms_shadow"], 2)}
+        # k_extend, per intersect ray: SURVEY.md §8(d): 64 B per binary node, 48 B per triangle, 16 B per sphere, 48 B of ray I/O, plus the
+        # shading-side fetch per hit (80 B triangle normals + material, 32 B sphere)
+        n_closest = max(sc["rays_closest"], 1)
+        b_ext = (64.0 * sc["closest_inner"] + 48.0 * sc["closest_tris"] + 16.0 * sc["closest_sphs"]) / n_closest + 48.0 \
+            + (80.0 * sc["closest_hits_tri"] + 32.0 * sc["closest_hits_sph"]) / n_closest
+        kernels["k_extend"] = {
+            "what": "Scene::intersect: closest hit on the binary SAH tree (while-while, rank tie-break)",
+            "unit": "intersect ray", "bytes_per_unit": round(b_ext, 1), "units_per_launch": round(cnt["rays_closest"] / max(cnt["launches_closest"], 1), 1),
+            "launches_per_step": int(cnt["launches_closest"]), "ms_per_step": round(cnt["kernel_ms_closest"], 2)}
+        frame_ms = cnt["kernel_ms_shadow"] + cnt["kernel_ms_light"] + cnt["kernel_ms_closest"] + cnt["kernel_ms_shade"]
+        pmc = pmc_kernels(a)
+        for name, k in kernels.items():
+            k["avg_launch_ms"] = round(k["ms_per_step"] / max(k["launches_per_step"], 1), 4)
+            k["share_of_kernel_time"] = round(k["ms_per_step"] / max(frame_ms, 1e-9), 4)
+            k["achieved_GBps"] = round(k["bytes_per_unit"] * k["units_per_launch"] / max(k["avg_launch_ms"], 1e-9) / 1e6, 2)
+            k["frac_of_hbm_peak"] = round(k["achieved_GBps"] / HBM_PEAK_GBS, 5)
+            m = pmc.get(name, {})
+            k["traffic"] = m.get("hbm_bytes_per_launch")
+            for f in ("l2_hit_rate", "valu_issue_busy", "valu_active_lanes", "valu_insts_per_launch"):
+                if f in m:
+                    k[f] = m[f]
+        dom = max(kernels, key=lambda n: kernels[n]["ms_per_step"])
+        d = kernels[dom]
         roofline = {
-            "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": kernel, "per_traced_ray": per_ray,
-            "bytes_per_ray": round(bytes_per_ray, 1), "rays_per_launch": round(rays_per_launch, 1), "avg_launch_ms": round(avg_ms, 4),
-            "launches_per_step": int(launches),
-            "kernel_ms_per_step": {"k_trace_p": round(cnt["kernel_ms_shadow"], 2), "k_light+k_binary": round(cnt["kernel_ms_light"], 2),
-                                   "k_extend": round(cnt["kernel_ms_closest"], 2), "shade+generate+resolve": round(cnt["kernel_ms_shade"], 2)},
-            "k_extend_bytes_per_ray": round(bytes_per_closest_ray, 1),
-            "k_extend_GBps": round(bytes_per_closest_ray * cnt["rays_closest"] / max(cnt["kernel_ms_closest"], 1e-9) / 1e6, 2),
-            "note": "algorithmic bytes over kernel time; the scene (%.0f MB) is resident in L2 / Infinity Cache, so this rate is served by the caches and may "
-                    "exceed the HBM peak, while `traffic` (HBM bytes per launch from the PMC counters) stays far below the algorithmic bytes "
-                    "(SURVEY.md §8d, DESIGN.md §6)" % (scene.info.device_bytes / 1e6),
+            "bound": "hbm", "achieved": d["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["frac_of_hbm_peak"],
+            "traffic": d["traffic"], "traffic_source": pmc.get("_source"),
+            "kernel": "%s (%s)" % (dom, d["what"]), "bytes_per_unit": d["bytes_per_unit"], "unit_of_work": d["unit"],
+            "units_per_launch": d["units_per_launch"], "avg_launch_ms": d["avg_launch_ms"], "launches_per_step": d["launches_per_step"],
+            "limiter": {"kind": "VALU issue", "valu_issue_busy": d.get("valu_issue_busy"), "valu_active_lanes": d.get("valu_active_lanes"),
+                        "valu_insts_per_launch": d.get("valu_insts_per_launch"),
+                        "note": "valu_issue_busy = fraction of all SIMD cycles of the kernel's run time with a VALU instruction executing "
+                                "(rocprofv3 --pmc SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE; profiles/); at ~1.0 the kernel is bound by instruction "
+                                "issue, not by HBM, so frac is low by construction (SURVEY.md §8d)"},
+            "kernels": kernels,
+            "kernel_ms_per_step": {"k_light": round(cnt["kernel_ms_light"], 2), "k_trace_p": round(cnt["kernel_ms_shadow"], 2),
+                                   "k_extend": round(cnt["kernel_ms_closest"], 2), "shade+generate+resolve+k_binary": round(cnt["kernel_ms_shade"], 2)},
+            "note": "achieved = algorithmic bytes per launch / HIP-event launch time of the dominant kernel; the scene (%.0f MB) is resident in L2 / "
+                    "Infinity Cache, so `traffic` (L2<->fabric bytes per launch from the TCC counters) is served mostly by the Infinity Cache"
+                    % (scene.info.device_bytes / 1e6),
         }
 
     # ---- CPU baseline: the oracle (reference algorithm, unpruned traversal, recursive integrator) on a bounded sample ----
@@ -216,23 +251,22 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(a, kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_pmc.json, written by
-    tools/summarize_prof.py from FETCH_SIZE / WRITE_SIZE collected in their own passes and corrected as MI355X_MICROARCH.md
-    prescribes).  bench.py cannot collect PMC counters on itself; the figure is only reported for the workload it was measured on."""
+def pmc_kernels(a):
+    """Per-kernel PMC figures of the committed rocprofv3 passes (profiles/r01_pmc.json, written by tools/summarize_prof.py): HBM-side
+    bytes per launch from FETCH_SIZE / WRITE_SIZE (own passes, corrected as MI355X_MICROARCH.md prescribes), L2 hit rate, VALU issue
+    utilisation.  bench.py cannot collect PMC counters on itself; the figures are only reported for the workload they were measured on."""
     path = os.path.join(ROOT, "profiles", "r01_pmc.json")
     try:
         with open(path) as f:
             j = json.load(f)
     except (OSError, ValueError):
-        return None, None
+        return {}
     w = j.get("workload", {})
     if (w.get("width"), w.get("height"), w.get("light_samples"), w.get("bounces"), w.get("mesh")) != (a.width, a.height, a.light_samples, a.bounces, a.mesh):
-        return None, None
-    k = j.get("kernels", {}).get(kernel)
-    if not k or k.get("hbm_bytes_per_launch") is None:
-        return None, None
-    return k["hbm_bytes_per_launch"], "profiles/r01_pmc.json (%s)" % j.get("source", "")
+        return {}
+    out = dict(j.get("kernels", {}))
+    out["_source"] = "profiles/r01_pmc.json (%s)" % j.get("source", "")
+    return out
 
 
 def cpu_baseline(a, standin, dragon_obj, target_s):

@@ -49,7 +49,7 @@ struct DevBuf {
 
 struct EventPair {
     hipEvent_t a, b;
-    int cls;   // 0 closest, 1 shadow, 2 shade/other, 3 light sampling (k_light)
+    int cls;   // 0 closest, 1 shadow, 2 shade/other (k_binary too), 3 light sampling (k_light alone)
 };
 
 }  // namespace
@@ -471,6 +471,8 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
                         else if (s->opt_light_waves >= 6) hipLaunchKernelGGL((k_light<false, 6, false>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
                         else if (s->opt_light_waves >= 5) hipLaunchKernelGGL((k_light<false, 5, false>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
                         else hipLaunchKernelGGL((k_light<false, 4, false>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                        end_timing(s, stream, ev);
+                        begin_timing(s, stream, 2, &ev);
                         if (s->opt_stats) hipLaunchKernelGGL(k_binary<true>, dim3(64), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
                         else hipLaunchKernelGGL(k_binary<false>, dim3(64), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
                         end_timing(s, stream, ev);

@@ -18,6 +18,40 @@ def short(name):
     return m.group(1) if m else None
 
 
+N_SIMD, N_XCD = 1024, 8
+
+
+def valu_busy(a):
+    return a.get("SQ_ACTIVE_INST_VALU", 0) * 4.0 / max(N_SIMD * a.get("GRBM_GUI_ACTIVE", 0) / N_XCD, 1)
+
+
+def per_bounce(per_disp):
+    """k_extend / k_light / k_trace_p run once per path level (bounce) and pass, in level order: dispatch i of a kernel is level i mod levels."""
+    out = ["## Per bounce (level = dispatch index modulo the launches per pass; sums over the passes of the run)", "",
+           "| kernel | level | waves | VALU instructions | active lanes | VALU issue busy |", "|---|---|---|---|---|---|"]
+    for k in sorted(per_disp):
+        base = k.split("<")[0]
+        if base not in ("k_extend", "k_light", "k_trace_p"):
+            continue
+        d = per_disp[k]
+        need = ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "GRBM_GUI_ACTIVE")
+        if any(c not in d for c in need):
+            continue
+        n = len(d["SQ_WAVES"])
+        per_pass = 9 if base == "k_extend" else 8
+        if n % per_pass:
+            continue
+        rows = defaultdict(lambda: defaultdict(float))
+        for c in need:
+            for i, (_, v) in enumerate(sorted(d[c])):
+                rows[i % per_pass][c] += v
+        for lv in range(per_pass):
+            r = rows[lv]
+            out.append("| `%s` | %d | %d | %.4g | %.3f | %.3f |" % (k, lv, r["SQ_WAVES"], r["SQ_INSTS_VALU"],
+                       r["SQ_THREAD_CYCLES_VALU"] / max(64.0 * r["SQ_ACTIVE_INST_VALU"], 1), valu_busy(r)))
+    return out + [""]
+
+
 def main(src, dst):
     out = ["# rocprofv3 summary: %s" % os.path.basename(src.rstrip("/")), ""]
     for line in (open(os.path.join(src, "trace.log")) if os.path.exists(os.path.join(src, "trace.log")) else []):
@@ -34,6 +68,7 @@ def main(src, dst):
     # PMC: sum each counter over the dispatches of each of our kernels
     agg = defaultdict(lambda: defaultdict(float))
     calls = defaultdict(lambda: defaultdict(int))
+    per_disp = defaultdict(lambda: defaultdict(list))   # kernel -> counter -> [(dispatch id, value)]
     meta = {}
     for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
@@ -42,6 +77,7 @@ def main(src, dst):
                 continue
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             calls[k][r["Counter_Name"]] += 1
+            per_disp[k][r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
             meta[k] = (r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Scratch_Size"])
     if agg:
         out += ["## PMC counters (separate `--pmc` passes; sums over all dispatches of the kernel in the run)", ""]
@@ -51,20 +87,24 @@ def main(src, dst):
             m = meta[k]
             out.append("| `%s` | %s | %s | %s | %s | " % (k, m[0], m[2], m[3], m[4]) + " | ".join("%.4g" % agg[k].get(c, float("nan")) for c in counters) + " |")
         out += ["", "## Derived (per kernel)", "",
-                "| kernel | dispatches | VALU lane utilisation = THREAD_CYCLES_VALU / (ACTIVE_INST_VALU*64)... see note | VALU busy = ACTIVE_INST_VALU*4 / WAVE_CYCLES... | L2 hit rate | FETCH GB (x2 corrected) | WRITE GB |",
-                "|---|---|---|---|---|---|---|"]
+                "| kernel | dispatches | active lanes per VALU instruction | VALU issue busy | waves resident per SIMD | L2 hit rate | FETCH GB (x2 corrected) | WRITE GB |",
+                "|---|---|---|---|---|---|---|---|"]
         for k in sorted(agg):
             a = agg[k]
             lane = a.get("SQ_THREAD_CYCLES_VALU", 0) / max(a.get("SQ_ACTIVE_INST_VALU", 0) * 64.0, 1)
-            busy = a.get("SQ_ACTIVE_INST_VALU", 0) / max(a.get("SQ_WAVE_CYCLES", 0), 1)
+            busy = valu_busy(a)
+            occ = a.get("SQ_WAVE_CYCLES", 0) * 4.0 / max(N_SIMD * a.get("GRBM_GUI_ACTIVE", 0) / N_XCD, 1)
             hit = a.get("TCC_HIT_sum", 0) / max(a.get("TCC_HIT_sum", 0) + a.get("TCC_MISS_sum", 0), 1)
             # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB; gfx950 FETCH_SIZE reads 1/2 of wide coalesced reads (MI355X_MICROARCH.md §HBM)
             fetch = a.get("FETCH_SIZE", 0) * 1024 * 2 / 1e9
             write = a.get("WRITE_SIZE", 0) * 1024 / 1e9
-            out.append("| `%s` | %d | %.3f | %.3f | %.4f | %.3f | %.3f |" % (k, calls[k].get("SQ_WAVES", 0), lane, busy, hit, fetch, write))
-        out += ["", "Notes: SQ_*_CYCLES counters are in quad-cycles (MI355X_MICROARCH.md); lane utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU) "
-                "is the mean fraction of the 64 lanes active per VALU instruction; 'VALU busy' = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES is the fraction of "
-                "wave-resident time spent issuing VALU work.", ""]
+            out.append("| `%s` | %d | %.3f | %.3f | %.2f | %.4f | %.3f | %.3f |" % (k, calls[k].get("SQ_WAVES", 0), lane, busy, occ, hit, fetch, write))
+        out += ["", "Notes: SQ_*_CYCLES / SQ_ACTIVE_* counters are in quad-cycles (MI355X_MICROARCH.md) and are summed over the chip; GRBM_GUI_ACTIVE is summed "
+                "over the 8 XCDs.  'active lanes' = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU): the mean fraction of the 64 lanes enabled per VALU "
+                "instruction.  'VALU issue busy' = 4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE / 8): the fraction of all SIMD cycles of the kernel's "
+                "run time in which the SIMD's VALU was executing (a wave64 instruction occupies its SIMD's 16-lane VALU for 4 cycles; counters of different "
+                "passes come from different runs, so a ratio can exceed 1 by a few percent).  'waves resident' = 4 * SQ_WAVE_CYCLES over the same denominator.", ""]
+        out += per_bounce(per_disp)
     os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
     open(dst, "w").write("\n".join(out) + "\n")
     print("\n".join(out))
@@ -92,12 +132,17 @@ def write_pmc_json(agg, calls, src, path, workload):
         e["variants"].append(k)
         if "TCC_HIT_sum" in a:
             e["l2_hit_rate"] = round(a["TCC_HIT_sum"] / max(a["TCC_HIT_sum"] + a.get("TCC_MISS_sum", 0), 1), 4)
+        if "SQ_ACTIVE_INST_VALU" in a and "GRBM_GUI_ACTIVE" in a:
+            e["valu_issue_busy"] = round(valu_busy(a), 4)
+            e["valu_active_lanes"] = round(a.get("SQ_THREAD_CYCLES_VALU", 0) / max(64.0 * a["SQ_ACTIVE_INST_VALU"], 1), 4)
+            e["valu_insts_per_launch"] = round(a.get("SQ_INSTS_VALU", 0) / max(calls[k].get("SQ_INSTS_VALU", 1), 1))
     for e in kernels.values():
         e["hbm_bytes_per_launch"] = round(e["fetch_bytes_per_launch"] + e["write_bytes_per_launch"])
         e["fetch_bytes_per_launch"] = round(e["fetch_bytes_per_launch"])
         e["write_bytes_per_launch"] = round(e["write_bytes_per_launch"])
     j = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of tools/profile.sh, %s" % os.path.basename(src.rstrip("/")),
          "correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950 counts 128-B requests as 64 B) + WRITE_SIZE KiB x 1024, averaged over the kernel's dispatches",
+         "valu": "valu_issue_busy = 4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs); valu_active_lanes = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)",
          "workload": workload, "kernels": kernels}
     open(path, "w").write(json.dumps(j, indent=1) + "\n")
 
