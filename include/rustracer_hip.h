@@ -77,7 +77,7 @@ typedef struct rt_counters {
     double   kernel_ms_closest, kernel_ms_shadow, kernel_ms_shade;  /* HIP-event time per kernel class (timing enabled) */
     uint64_t launches_closest, launches_shadow;
     uint64_t shadow_wide;     /* 8-wide occlusion-BVH nodes (80 B) fetched by is_occluded rays ("stats" on) */
-    double   kernel_ms_light; /* HIP-event time of the light-sampling kernel (Object::sample_l + the self test), timing enabled */
+    double   kernel_ms_light; /* HIP-event time of k_light alone (Object::sample_l, own-object test, occluder cache), timing enabled */
     uint64_t trace_steps[8];  /* persistent traversal kernel, "stats" on: wave-wide node steps, lanes in them, primitive steps, lanes, refills, lanes,
                                * primitive records whose own box the ray misses (false candidates of the quantised tree), spare */
 } rt_counters;
@@ -129,8 +129,12 @@ int rt_intersect_rays(rt_scene* scene, const float* origins, const float* direct
 int rt_occluded_rays(rt_scene* scene, const float* origins, const float* directions, const float* max_dist, uint32_t n, uint8_t* out);
 
 int rt_get_counters(const rt_scene* scene, rt_counters* out);
-/* Options: "stats" (0/1 traversal counters), "timing" (0/1 HIP-event kernel timing),
- * "max_paths" (paths in flight per pass), "wide" (0/1: is_occluded rays use the 8-wide occlusion BVH, default 1). */
+/* Options (none changes a result; all but the first three are tuning switches the parity tests flip):
+ *   "stats" 0/1 traversal counters; "timing" 0/1 HIP-event kernel timing; "max_paths" camera samples in flight per pass;
+ *   "wide" 0/1 is_occluded rays use the 8-wide occlusion BVH (default 1); "persist" 0/1 light samples go through the
+ *   k_light + persistent k_trace_p pair (default 1); "hot" 0/1 per-light occluder cache (default 1; only before the first
+ *   render); "self_test" 0/1 test the object a shadow ray starts on first (default 1); "root_in_light" 0/1 (default 0);
+ *   "refill_min" (16), "phase_bias" (4), "shadow_waves" (8), "light_waves" (4), "inner_min" (12): scheduling constants. */
 int rt_set_option(rt_scene* scene, const char* name, uint64_t value);
 
 /* Screen tiles (no reference counterpart): pack the owned tiles of a frame into a
