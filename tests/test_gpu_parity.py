@@ -241,6 +241,36 @@ def test_two_lights_odd_sample_counts_and_moved_camera(gpu, w, h, spp, L, b, cam
         assert np.array_equal(alt, ref["rgba"]), opt
 
 
+def test_occluder_cache_and_scheduling_switches_do_not_change_a_pixel(gpu):
+    """The per-light occluder cache ("hot", fixed at the first render), the root-node test in k_light, the own-object test and the
+    scheduling constants of k_trace_p are search-order choices only: every combination gives the oracle's image and ray counts."""
+    op = oracle_params(width=56, height=48, spp=3, light_samples=6, bounces=5, seed=7)
+    osc, gsc = _two_light_scene()
+    ref = osc.render(op)
+    p = to_rt_params(op)
+    for opts in ({}, {"root_in_light": 1}, {"self_test": 0}, {"refill_min": 1, "phase_bias": 1}, {"refill_min": 64, "phase_bias": 16, "shadow_waves": 5},
+                 {"light_waves": 8, "root_in_light": 0}):
+        for k, v in opts.items():
+            gsc.set_option(k, v)
+        got, cnt = gpu_render(gsc, p)
+        assert np.array_equal(got, ref["rgba"]), opts
+        assert cnt["rays_shadow"] == ref["occluded_calls"], opts
+        for k, v in {"root_in_light": 0, "self_test": 1, "refill_min": 16, "phase_bias": 4, "shadow_waves": 8, "light_waves": 4}.items():
+            gsc.set_option(k, v)
+    with pytest.raises(Exception):
+        gsc.set_option("hot", 0)                           # the cache is chosen at the first render
+    _, cold = _two_light_scene()
+    cold.set_option("hot", 0)
+    got, _ = gpu_render(cold, p)
+    assert np.array_equal(got, ref["rgba"]), "hot=0"
+    cold.set_option("stats", 1)
+    _, c_cold = gpu_render(cold, p)
+    gsc.set_option("stats", 1)
+    _, c_hot = gpu_render(gsc, p)
+    gsc.set_option("stats", 0)
+    assert 0 < c_hot["trace_steps"][5] < c_cold["trace_steps"][5]      # rays handed to k_trace_p: fewer with the cache
+
+
 def test_axis_aligned_shadow_rays_take_the_binary_tree(gpu):
     """Light sampling almost never produces a direction with a zero component, so Scene::is_occluded is driven directly:
     rays with zero, denormal and tiny direction components (the 0 * inf = NaN cases of the slab test, which leave the 8-wide
