@@ -8,7 +8,9 @@
 
 #include <math.h>
 
+#include <atomic>
 #include <limits>
+#include <thread>
 
 #include "rt_math.h"
 
@@ -304,6 +306,34 @@ void make_dragon_standin(uint32_t nu, uint32_t nv, float* vpos, float* vnrm, uin
 // array partitioned in place (bucket by bucket, which is the order the crate concatenates in).
 namespace {
 
+// Worker threads of the host builders: RT_HOST_THREADS, else OMP_NUM_THREADS, else the hardware's count, at most 16 (a GPU
+// box reports every CPU of the machine while a job owns a share of them).
+unsigned host_threads() {
+    for (const char* name : {"RT_HOST_THREADS", "OMP_NUM_THREADS"}) {
+        const char* v = getenv(name);
+        if (v && *v) {
+            const long n = strtol(v, nullptr, 10);
+            if (n >= 1) return n > 64 ? 64u : (unsigned)n;
+        }
+    }
+    const unsigned hc = std::thread::hardware_concurrency();
+    return hc == 0 ? 1u : (hc > 16 ? 16u : hc);
+}
+
+// f(begin, end) over [0, n) in at most host_threads() contiguous pieces of at least `grain` items.
+template <class F>
+void parallel_for(size_t n, size_t grain, F f) {
+    const size_t nt = host_threads();
+    size_t pieces = grain ? n / grain : 1;
+    if (pieces > nt) pieces = nt;
+    if (pieces <= 1) { f((size_t)0, n); return; }
+    std::vector<std::thread> th;
+    th.reserve(pieces - 1);
+    for (size_t c = 1; c < pieces; ++c) th.emplace_back([=] { f(c * n / pieces, (c + 1) * n / pieces); });
+    f((size_t)0, n / pieces);
+    for (size_t c = 0; c < th.size(); ++c) th[c].join();
+}
+
 struct Box {
     float mn[3], mx[3];
 };
@@ -344,18 +374,24 @@ class Builder {
         idx_.resize(n);
         tmp_.resize(n);
         for (uint32_t i = 0; i < n; ++i) idx_[i] = i;
-        out_->words.clear();
-        out_->depth = 0;
-        out_->root = n ? split(0, n, 1) : LEAF_BIT;
-        assign_ranks(n);
+        // One shape per leaf: a subtree over m shapes has m - 1 inner nodes, so the pre-order index of every node and the rank
+        // (position in the reference's right-first DFS, mod.rs:427-432) of every leaf are known before the subtree is built, and
+        // disjoint subtrees can be built by different threads with the result of the sequential recursion.
+        out_->words.assign(n > 1 ? 16 * (size_t)(n - 1) : 0, 0u);
+        out_->rank.assign(n, 0u);
+        depth_.store(0);
+        grain_ = n / (4 * host_threads());
+        if (grain_ < 4096) grain_ = 4096;
+        out_->root = n ? split(0, n, 1, 0, 0) : LEAF_BIT;
+        out_->depth = depth_.load();
     }
 
   private:
-    uint32_t split(uint32_t b, uint32_t e, uint32_t level) {
-        if (e - b == 1) return LEAF_BIT | idx_[b];
-        if (level > out_->depth) out_->depth = level;
-        const uint32_t me = (uint32_t)(out_->words.size() / 16);
-        out_->words.resize(out_->words.size() + 16, 0u);
+    // [b, e) of idx_, tree level, pre-order index of the node if it is an inner one, rank of the first leaf visited
+    uint32_t split(uint32_t b, uint32_t e, uint32_t level, uint32_t me, uint32_t rank0) {
+        if (e - b == 1) { out_->rank[idx_[b]] = rank0; return LEAF_BIT | idx_[b]; }
+        uint32_t seen = depth_.load(std::memory_order_relaxed);
+        while (level > seen && !depth_.compare_exchange_weak(seen, level, std::memory_order_relaxed)) {}
 
         Box all = empty_box(), cb = empty_box();
         for (uint32_t k = b; k < e; ++k) {
@@ -400,9 +436,10 @@ class Builder {
             for (int i = 0; i < NB; ++i) start[i + 1] = start[i] + cnt[i];
             uint32_t fill[NB];
             for (int i = 0; i < NB; ++i) fill[i] = start[i];
-            scratch_.resize(e - b);
-            for (uint32_t k = b; k < e; ++k) scratch_[fill[tmp_[k]]++] = idx_[k];
-            for (uint32_t k = b; k < e; ++k) idx_[k] = scratch_[k - b];
+            static thread_local std::vector<uint32_t> scratch;
+            if (scratch.size() < e - b) scratch.resize(e - b);
+            for (uint32_t k = b; k < e; ++k) scratch[fill[tmp_[k]]++] = idx_[k];
+            for (uint32_t k = b; k < e; ++k) idx_[k] = scratch[k - b];
             const int cut = best < 0 ? 0 : best;
             mid = b + start[cut + 1];
             if (best < 0 || mid == b || mid == e) halved = true;   // every cost NaN: degenerate bounds
@@ -413,8 +450,17 @@ class Builder {
             for (uint32_t k = b; k < mid; ++k) join_into(&lbox, box_[idx_[k]]);
             for (uint32_t k = mid; k < e; ++k) join_into(&rbox, box_[idx_[k]]);
         }
-        const uint32_t left = split(b, mid, level + 1);
-        const uint32_t right = split(mid, e, level + 1);
+        // pre-order: the left subtree's mid - b - 1 inner nodes follow this one; right-first DFS: the right subtree's e - mid leaves rank first
+        const uint32_t left_me = me + 1, right_me = me + (mid - b), left_rank = rank0 + (e - mid);
+        uint32_t left, right;
+        if (mid - b >= grain_ && e - mid >= grain_) {
+            std::thread other([&] { left = split(b, mid, level + 1, left_me, left_rank); });
+            right = split(mid, e, level + 1, right_me, rank0);
+            other.join();
+        } else {
+            left = split(b, mid, level + 1, left_me, left_rank);
+            right = split(mid, e, level + 1, right_me, rank0);
+        }
         uint32_t* w = &out_->words[16 * (size_t)me];
         memcpy(w + 0, lbox.mn, 12); memcpy(w + 3, lbox.mx, 12);
         memcpy(w + 6, rbox.mn, 12); memcpy(w + 9, rbox.mx, 12);
@@ -422,25 +468,12 @@ class Builder {
         return me;
     }
 
-    void assign_ranks(uint32_t n) {
-        out_->rank.assign(n, 0u);
-        if (!n) return;
-        std::vector<uint32_t> st;
-        st.push_back(out_->root);
-        uint32_t next = 0;
-        while (!st.empty()) {
-            const uint32_t ref = st.back();
-            st.pop_back();
-            if (ref & LEAF_BIT) { out_->rank[ref & ~LEAF_BIT] = next++; continue; }
-            st.push_back(out_->words[16 * (size_t)ref + 12]);   // left pushed first ...
-            st.push_back(out_->words[16 * (size_t)ref + 13]);   // ... so right is popped first (mod.rs:427-432)
-        }
-    }
-
     FlatBVH* out_;
     std::vector<Box> box_;
     std::vector<float> ctr_;
-    std::vector<uint32_t> idx_, tmp_, scratch_;
+    std::vector<uint32_t> idx_, tmp_;
+    std::atomic<uint32_t> depth_;
+    uint32_t grain_ = 4096;
 };
 
 }  // namespace
@@ -483,33 +516,54 @@ class WideBuilder {
         for (size_t i = 0; i < sc.sph.size(); ++i)
             if (!(fabsf(sc.sph[i]) <= WIDE_COORD_MAX / 2.0f)) return;
 
-        // breadth-first: the inner children of a node get consecutive node indices, its primitives consecutive records
-        struct Item { uint32_t ref; uint32_t level; };
-        std::vector<Item> queue;
-        queue.push_back(Item{bvh.root, 1});
-        out_->nodes.resize(20, 0u);
-        size_t head = 0;
-        bool ok = true;
-        while (head < queue.size() && ok) {
-            const Item it = queue[head];
-            const uint32_t me = (uint32_t)head;
-            ++head;
-            if (it.level > out_->depth) out_->depth = it.level;
-            std::vector<WChild> ch;
-            gather_children(it.ref, &ch);
-            // inner children first
-            std::vector<WChild> inner, prim;
-            for (size_t k = 0; k < ch.size(); ++k) ((ch[k].ref & LEAF_BIT) ? prim : inner).push_back(ch[k]);
-            const uint32_t child_base = (uint32_t)queue.size();
-            const uint32_t prim_base = out_->n_prims();
-            for (size_t k = 0; k < inner.size(); ++k) queue.push_back(Item{inner[k].ref, it.level + 1});
-            out_->nodes.resize(20 * queue.size(), 0u);
-            for (size_t k = 0; k < prim.size(); ++k) emit_prim(prim[k].ref & OBJECT_MASK);
-            std::vector<WChild> all(inner);
-            all.insert(all.end(), prim.begin(), prim.end());
-            ok = write_node(me, all, (uint32_t)inner.size(), child_base, prim_base);
+        // Breadth-first: the inner children of a node get consecutive node indices, its primitives consecutive records.  One tree
+        // level at a time: the nodes of a level are collapsed and quantised by several threads; the child and record indices in
+        // between are running sums in node order, which is the order a sequential queue would hand them out in.
+        struct Gathered { std::vector<WChild> ch; uint32_t n_inner; };
+        std::vector<uint32_t> refs(1, bvh.root), next_refs, child_base, prim_base;
+        std::vector<Gathered> g;
+        uint32_t level_base = 0, n_prims = 0;
+        out_->nodes.assign(20, 0u);
+        std::atomic<bool> ok(true);
+        while (!refs.empty() && ok.load()) {
+            ++out_->depth;
+            const size_t m = refs.size();
+            g.assign(m, Gathered());
+            parallel_for(m, 512, [&](size_t b, size_t e) {
+                std::vector<WChild> ch;
+                for (size_t i = b; i < e; ++i) {
+                    ch.clear();
+                    gather_children(refs[i], &ch);
+                    Gathered& gi = g[i];   // inner children first
+                    for (size_t k = 0; k < ch.size(); ++k) if (!(ch[k].ref & LEAF_BIT)) gi.ch.push_back(ch[k]);
+                    gi.n_inner = (uint32_t)gi.ch.size();
+                    for (size_t k = 0; k < ch.size(); ++k) if (ch[k].ref & LEAF_BIT) gi.ch.push_back(ch[k]);
+                }
+            });
+            child_base.resize(m); prim_base.resize(m);
+            const uint64_t next_base = (uint64_t)level_base + m;
+            uint64_t nn = next_base, np = n_prims;
+            for (size_t i = 0; i < m; ++i) {
+                child_base[i] = (uint32_t)nn; nn += g[i].n_inner;
+                prim_base[i] = (uint32_t)np; np += g[i].ch.size() - g[i].n_inner;
+            }
+            if (nn >= (1u << 23) || np + 8 >= (1u << 23)) { ok.store(false); break; }   // index fields of the stack entries (rt_kernels.h)
+            out_->nodes.resize(20 * (size_t)nn, 0u);
+            out_->prims.resize(12 * (size_t)np, 0.0f);
+            next_refs.assign((size_t)(nn - next_base), 0u);
+            parallel_for(m, 512, [&](size_t b, size_t e) {
+                for (size_t i = b; i < e; ++i) {
+                    const Gathered& gi = g[i];
+                    for (uint32_t k = 0; k < gi.n_inner; ++k) next_refs[child_base[i] - next_base + k] = gi.ch[k].ref;
+                    for (size_t k = gi.n_inner; k < gi.ch.size(); ++k) emit_prim(gi.ch[k].ref & OBJECT_MASK, prim_base[i] + (uint32_t)(k - gi.n_inner));
+                    if (!write_node(level_base + (uint32_t)i, gi.ch, gi.n_inner, child_base[i], prim_base[i])) ok.store(false);
+                }
+            });
+            level_base = (uint32_t)next_base;
+            n_prims = (uint32_t)np;
+            refs.swap(next_refs);
         }
-        if (!ok || queue.size() >= (1u << 23) || out_->n_prims() + 8 >= (1u << 23)) {
+        if (!ok.load()) {
             out_->nodes.clear(); out_->prims.clear(); out_->depth = 0;
             return;
         }
@@ -572,10 +626,10 @@ class WideBuilder {
         }
     }
 
-    void emit_prim(uint32_t obj) {
+    void emit_prim(uint32_t obj, uint32_t rec) {
         const uint32_t T = sc_.n_tri();
-        out_->rec_of_obj[obj] = out_->n_prims();
-        float r[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        out_->rec_of_obj[obj] = rec;
+        float* r = &out_->prims[12 * (size_t)rec];   // zero-filled by the caller
         if (obj < T) {
             const float* p = &sc_.tri_pos[9 * (size_t)obj];
             r[0] = p[0]; r[1] = p[1]; r[2] = p[2]; r[3] = bits_to_float(0u);
@@ -586,7 +640,6 @@ class WideBuilder {
             r[0] = c[0]; r[1] = c[1]; r[2] = c[2]; r[3] = bits_to_float(1u);
             r[4] = c[3]; r[5] = bits_to_float(obj);
         }
-        out_->prims.insert(out_->prims.end(), r, r + 12);
     }
 
     bool write_node(uint32_t me, const std::vector<WChild>& ch, uint32_t n_inner, uint32_t child_base, uint32_t prim_base) {

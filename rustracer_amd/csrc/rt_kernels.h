@@ -1127,13 +1127,15 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
                 skip_rec = __float_as_uint(I4.w) & RT_W_NO_REC;                // the object the ray starts on: tested by k_light
                 br.sx = I4.x < 0.0f; br.sy = I4.y < 0.0f; br.sz = I4.z < 0.0f; // sign of the normalised direction (finite 1/d only: wide_ray_ok)
                 lim = prune_limit(max_dist);
-                // k_light has tested the root node: the ray starts at the root's hit slots
-                uint32_t a, b;
-                wide_groups(__float_as_uint(I4.w) >> 23, root_meta, root_child, root_prim, skip_rec, &a, &b);
                 st.sp = 0;
-                if (a && b) st.push(b);
-                cur = a ? a : b;
-                if (!sc.root_in_light) cur = 1u;      // inner group {node 0}
+                if (sc.root_in_light) {               // k_light has tested the root node: the ray starts at the root's hit slots
+                    uint32_t a, b;
+                    wide_groups(__float_as_uint(I4.w) >> 23, root_meta, root_child, root_prim, skip_rec, &a, &b);
+                    if (a && b) st.push(b);
+                    cur = a ? a : b;
+                } else {
+                    cur = 1u;                         // inner group {node 0}
+                }
             }
             __builtin_amdgcn_wave_barrier();
             continue;

@@ -100,6 +100,35 @@ def test_dragon_standin_is_deterministic_and_bvh_equals_oracle():
     assert list(p.light_indexes()) == [10 + 9600]
 
 
+def test_threaded_builders_equal_the_sequential_ones_and_the_oracle(monkeypatch):
+    """51,200 triangles: large enough for build_bvh to hand subtrees to other threads and for build_wide_bvh to split its levels.
+    Node indices (pre-order), ranks (right-first DFS) and the 8-wide tree must not depend on the thread count."""
+    vp, vn, f = ra.dragon_standin_mesh(400, 64)
+    built = {}
+    for threads in ("1", "3", "8"):
+        monkeypatch.setenv("RT_HOST_THREADS", threads)
+        p = ra.Scene.from_dragon_mesh(vp, vn, f)
+        words, rank = p.bvh()
+        nodes, prims = p.wide_bvh()
+        built[threads] = (words.copy(), rank.copy(), nodes.copy(), prims.copy(), p.info.bvh_depth, p.info.wide_depth)
+    for threads in ("3", "8"):
+        for a, b in zip(built["1"][:4], built[threads][:4]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), threads
+        assert built["1"][4:] == built[threads][4:]
+    words, rank = built["8"][0], built["8"][1]
+    o = ob.OracleScene.dragon_mesh(vp, vn, f)
+    assert np.array_equal(words, _oracle_inner_words(o))
+    order, stack = [], [0]                                  # rank = the reference's visiting order (mod.rs:427-432)
+    while stack:
+        ref = stack.pop()
+        if ref & 0x80000000:
+            order.append(ref & 0x7FFFFFFF)
+            continue
+        stack.append(int(words[ref, 12]))
+        stack.append(int(words[ref, 13]))
+    assert np.array_equal(rank[np.array(order)], np.arange(len(order), dtype=rank.dtype))
+
+
 def test_obj_loader_polygons_first_model_and_missing_normals(tmp_path):
     """Scene::load_obj (mod.rs:135-189): fan triangulation, models[0] only, flat normals when `vn` is absent."""
     path = tmp_path / "dragon.obj"
