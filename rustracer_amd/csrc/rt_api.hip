@@ -120,9 +120,47 @@ void prepare_host(rt_scene* s) {
                       (uint64_t)s->wide.n_nodes() * 80 + (uint64_t)s->wide.n_prims() * 48 + (uint64_t)s->wide.rec_of_obj.size() * 4;
 }
 
+// What the kernels assume about the two trees, checked on the host before anything is uploaded: every index a kernel follows
+// stays inside its array, so a malformed tree is an error here and not a memory fault there.
+bool trees_are_well_formed(const rt_scene* s, std::string* why) {
+    const uint32_t n_obj = s->host.n_tri() + s->host.n_sph();
+    const FlatBVH& b = s->bvh;
+    const uint32_t ni = b.n_inner();
+    if (b.rank.size() != n_obj) { *why = "rank table size"; return false; }
+    if (n_obj && !(b.root & LEAF_BIT) && b.root >= ni) { *why = "root index"; return false; }
+    for (uint32_t i = 0; i < ni; ++i)
+        for (int c = 12; c <= 13; ++c) {
+            const uint32_t ref = b.words[16 * (size_t)i + c];
+            if ((ref & LEAF_BIT) ? (ref & OBJECT_MASK) >= n_obj : (ref >= ni || ref <= i)) { *why = "binary node child reference"; return false; }
+        }
+    const WideBVH& w = s->wide;
+    if (!w.ok) return true;
+    const uint32_t nn = w.n_nodes(), np = w.n_prims();
+    if (!nn || w.rec_of_obj.size() != n_obj) { *why = "8-wide tree tables"; return false; }
+    for (uint32_t i = 0; i < nn; ++i) {
+        const uint32_t* q = &w.nodes[20 * (size_t)i];
+        const uint32_t n_inner = (q[3] >> 24) & 0xFu, n_child = q[3] >> 28;
+        if (n_child > 8 || n_inner > n_child) { *why = "8-wide node child counts"; return false; }
+        if (n_inner && ((uint64_t)q[4] + n_inner > nn || q[4] <= i)) { *why = "8-wide node child index"; return false; }
+        if (n_child > n_inner && (uint64_t)q[5] + (n_child - n_inner) > np) { *why = "8-wide node record index"; return false; }
+    }
+    for (uint32_t r = 0; r < np; ++r) {
+        const uint32_t kind = float_to_bits(w.prims[12 * (size_t)r + 3]);
+        const uint32_t obj = float_to_bits(w.prims[12 * (size_t)r + (kind == 0u ? 7 : 5)]);
+        if (kind > 1u || obj >= n_obj || w.rec_of_obj[obj] != r) { *why = "8-wide primitive record"; return false; }
+    }
+    for (uint32_t o = 0; o < n_obj; ++o)
+        if (w.rec_of_obj[o] != 0xFFFFFFFFu && w.rec_of_obj[o] >= np) { *why = "record-of-object table"; return false; }
+    return true;
+}
+
 // Device half: flatten to the kernel layout and upload, on first use.
 int upload_scene(rt_scene* s) {
     if (s->uploaded) return RT_OK;
+    {
+        std::string why;
+        if (!trees_are_well_formed(s, &why)) return fail(RT_ERR_INVALID, "scene trees failed the pre-upload check: " + why);
+    }
     const HostScene& h = s->host;
     const uint32_t T = h.n_tri(), S = h.n_sph(), M = (uint32_t)h.mats.size();
     const FlatBVH& b = s->bvh;
