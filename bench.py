@@ -195,7 +195,7 @@ def main():
             "unit": "intersect ray", "bytes_per_unit": round(b_ext, 1), "units_per_launch": round(cnt["rays_closest"] / max(cnt["launches_closest"], 1), 1),
             "launches_per_step": int(cnt["launches_closest"]), "ms_per_step": round(cnt["kernel_ms_closest"], 2)}
         frame_ms = cnt["kernel_ms_shadow"] + cnt["kernel_ms_light"] + cnt["kernel_ms_closest"] + cnt["kernel_ms_shade"]
-        pmc = pmc_kernels(a)
+        pmc = pmc_kernels(a) if world == 1 else {}   # the committed counters are of the one-GPU launch sizes
         for name, k in kernels.items():
             k["avg_launch_ms"] = round(k["ms_per_step"] / max(k["launches_per_step"], 1), 4)
             k["share_of_kernel_time"] = round(k["ms_per_step"] / max(frame_ms, 1e-9), 4)
@@ -228,7 +228,7 @@ def main():
 
     # ---- CPU baseline: the oracle (reference algorithm, unpruned traversal, recursive integrator) on a bounded sample ----
     cpu = None
-    if a.cpu_seconds > 0:
+    if a.cpu_seconds > 0 and world == 1:   # reported at N = 1 only (the host cores are shared by the ranks otherwise)
         cpu = cpu_baseline(a, standin if not os.path.exists(dragon_obj) else None, dragon_obj, a.cpu_seconds)
 
     value = rays_per_step * a.steps / elapsed / 1e6
