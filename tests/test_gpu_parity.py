@@ -444,3 +444,62 @@ def test_python_api_mirror_renders(gpu, teapot_obj, tmp_path, monkeypatch):
     rt.render(True)
     rt.reset_camera()
     assert rt.inner.camera_position == [0.0, 0.0, 0.0]
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE's full sizes: 1920x1080 over the 871,200-triangle dragon-class mesh (configs 3 and 4).
+@pytest.fixture(scope="module")
+def full_dragon(gpu):
+    from oracle import binding as ob
+    import rustracer_amd as ra
+    vp, vn, f = ra.dragon_standin_mesh(*ra.DRAGON_STANDIN_FULL)
+    return ob.OracleScene.dragon_mesh(vp, vn, f), ra.Scene.from_dragon_mesh(vp, vn, f)
+
+
+def test_full_size_primary_ids_bit_exact(full_dragon):
+    """Config 3 as BASELINE states it: every one of the 1920x1080 primary rays finds the oracle's object, at the oracle's distance."""
+    osc, gsc = full_dragon
+    op = oracle_params(width=1920, height=1080, spp=1, light_samples=1, bounces=1)
+    oi, ot, ocnt = osc.cast_primary(op)
+    gi, gt = gpu_cast(gsc, to_rt_params(op))
+    assert int(ocnt[0]) == 1920 * 1080
+    assert np.array_equal(gi, oi), "%d ids differ" % int((gi != oi).sum())
+    assert np.array_equal(gt.view(np.uint32), ot.view(np.uint32))
+    assert len(np.unique(gi)) > 20000                       # the mesh fills a good part of the frame
+
+
+def test_full_size_gi_tiles_match_oracle_and_shards_compose(full_dragon):
+    """Config 4's frame (1080p, 32 light samples, depth 8) at 2 spp: the oracle renders every 97th 32x32 tile and those pixels must be
+    bit-identical in the GPU frame; the frame must not depend on how it is cut into passes or shards (size-independent properties:
+    pixels are independent, RNG streams are keyed by the global pixel index)."""
+    osc, gsc = full_dragon
+    W, H, K = 1920, 1080, 97
+    op = oracle_params(width=W, height=H, spp=2, light_samples=32, bounces=8, seed=0x5EED, tile=(32, 32), shard=(0, K))
+    ref = osc.render(op)
+    full = oracle_params(width=W, height=H, spp=2, light_samples=32, bounces=8, seed=0x5EED)
+    p = to_rt_params(full)
+    got, cnt = gpu_render(gsc, p)
+    assert cnt["samples"] == W * H * 2 and cnt["rays_shadow"] % 32 == 0
+    tiles_x = W // 32
+    n_tiles = tiles_x * ((H + 31) // 32)
+    checked = 0
+    for t in range(0, n_tiles, K):
+        x0, y0 = (t % tiles_x) * 32, (t // tiles_x) * 32
+        a, b = got[y0:y0 + 32, x0:x0 + 32], ref["rgba"][y0:y0 + 32, x0:x0 + 32]
+        assert np.array_equal(a, b), "tile %d: %d bytes differ" % (t, int((a != b).sum()))
+        checked += a.shape[0] * a.shape[1]
+    assert checked >= 20 * 1024
+    # the same frame from 5 shards of 64x16 tiles, in smaller passes
+    from rustracer_amd._lib import check, lib, ptr
+    gsc.set_option("max_paths", 1 << 20)
+    frame = np.zeros((H, W, 4), np.uint8)
+    rays = 0
+    for shard in range(5):
+        q = p.copy()
+        q.tile_w, q.tile_h, q.shard_index, q.shard_count = 64, 16, shard, 5
+        check(lib().rt_render(gsc.handle, C.byref(q), ptr(frame), None, None))
+        c = gsc.counters()
+        rays += c["rays_closest"] + c["rays_shadow"]
+    gsc.set_option("max_paths", 0)
+    assert np.array_equal(frame, got)
+    assert rays == cnt["rays_closest"] + cnt["rays_shadow"]
