@@ -503,3 +503,25 @@ def test_full_size_gi_tiles_match_oracle_and_shards_compose(full_dragon):
     gsc.set_option("max_paths", 0)
     assert np.array_equal(frame, got)
     assert rays == cnt["rays_closest"] + cnt["rays_shadow"]
+
+
+@pytest.mark.parametrize("name,w,h,spp,L,b,est,stride", [
+    ("sphere_on_plane", 512, 512, 16, 8, 1, 1, 1),          # config 1 whole: hemisphere estimator, direct lighting
+    ("teapot", 1024, 1024, 64, 16, 1, 0, 64),               # config 2 at its own spp: every 64th tile
+    ("specular_teapot", 3840, 2160, 16, 32, 8, 0, 500),     # config 5's 4K frame at 16 of 1024 spp: every 500th tile
+])
+def test_baseline_configs_at_full_resolution(scenes, name, w, h, spp, L, b, est, stride):
+    """The other BASELINE configs at their full resolution: the oracle renders every `stride`-th 32x32 tile, the GPU the whole
+    frame; the oracle's tiles must be bit-identical in it."""
+    osc, gsc = scenes(name)
+    ref = osc.render(oracle_params(width=w, height=h, spp=spp, light_samples=L, bounces=b, direct_estimator=est, tile=(32, 32), shard=(0, stride)))
+    got, cnt = gpu_render(gsc, to_rt_params(oracle_params(width=w, height=h, spp=spp, light_samples=L, bounces=b, direct_estimator=est)))
+    assert cnt["samples"] == w * h * spp
+    tiles_x = (w + 31) // 32
+    n_tiles = tiles_x * ((h + 31) // 32)
+    for t in range(0, n_tiles, stride):
+        x0, y0 = (t % tiles_x) * 32, (t // tiles_x) * 32
+        a, r = got[y0:y0 + 32, x0:x0 + 32], ref["rgba"][y0:y0 + 32, x0:x0 + 32]
+        assert np.array_equal(a, r), "tile %d: %d bytes differ" % (t, int((a != r).sum()))
+    if stride == 1:
+        assert cnt["rays_closest"] == ref["intersect_calls"] and cnt["rays_shadow"] == ref["occluded_calls"]
