@@ -64,7 +64,8 @@ struct rt_scene {
 
     DevBuf<float4> d_nodes, d_tris, d_tri_nrm, d_sph, d_mats, d_wnodes, d_wprims;
     DevBuf<uint2> d_sph_aux;
-    DevBuf<uint32_t> d_lights, d_ovf, d_wrec, d_hot;
+    DevBuf<uint32_t> d_lights, d_ovf, d_wrec;
+    HotTable hot_table;
     DevScene dev;
     uint64_t device_bytes = 0;
 
@@ -118,6 +119,20 @@ void prepare_host(rt_scene* s) {
         if (!scene_is_black(h.mats[h.sph_mat[i]].emittance)) s->lights.push_back(T + i);
     s->device_bytes = (uint64_t)s->bvh.n_inner() * 64 + (uint64_t)T * 96 + (uint64_t)S * 24 + (uint64_t)h.mats.size() * 32 + s->lights.size() * 4 +
                       (uint64_t)s->wide.n_nodes() * 80 + (uint64_t)s->wide.n_prims() * 48 + (uint64_t)s->wide.rec_of_obj.size() * 4;
+}
+
+// Own box of a primitive record of the occlusion BVH: the same floats as Bounded for Triangle / Sphere (objects.rs:293-316) and as
+// lo3 / hi3 in the kernels.
+void record_box(const float* q, float* mn, float* mx) {
+    if (float_to_bits(q[3]) == 0u) {
+        for (int a = 0; a < 3; ++a) {
+            const float l = q[a] < q[4 + a] ? q[a] : q[4 + a], g = q[a] > q[4 + a] ? q[a] : q[4 + a];
+            mn[a] = l < q[8 + a] ? l : q[8 + a];
+            mx[a] = g > q[8 + a] ? g : q[8 + a];
+        }
+    } else {
+        for (int a = 0; a < 3; ++a) { mn[a] = q[a] - q[4]; mx[a] = q[a] + q[4]; }
+    }
 }
 
 // What the kernels assume about the two trees, checked on the host before anything is uploaded: every index a kernel follows
@@ -257,24 +272,18 @@ int upload_scene(rt_scene* s) {
     {
         // Occluder cache of k_light: per light, the RT_HOT largest non-emissive objects whose box overlaps the light's box (a light
         // recessed into or poking through a wall has most of its samples blocked by that wall).  A choice of test order only.
-        std::vector<uint32_t> hot(RT_HOT * (s->lights.empty() ? 1 : s->lights.size()), RT_W_NO_REC);
+        for (int li = 0; li < RT_HOT_LIGHTS; ++li)
+            for (int k = 0; k < RT_HOT; ++k) { memset(&s->hot_table.rec[li][k], 0, sizeof(HotRec)); s->hot_table.rec[li][k].kind = 2u; s->hot_table.rec[li][k].rec = RT_W_NO_REC; }
         if (s->wide.ok && s->opt_hot) {
-            for (size_t li = 0; li < s->lights.size(); ++li) {
+            for (size_t li = 0; li < s->lights.size() && li < RT_HOT_LIGHTS; ++li) {
                 if (s->lights[li] < T) continue;   // triangle lights are rejected before any sampling
                 const float* c = &h.sph[4 * (size_t)(s->lights[li] - T)];
                 float best_area[RT_HOT];
-                for (int k = 0; k < RT_HOT; ++k) best_area[k] = -1.0f;
+                uint32_t best_rec[RT_HOT];
+                for (int k = 0; k < RT_HOT; ++k) { best_area[k] = -1.0f; best_rec[k] = RT_W_NO_REC; }
                 for (uint32_t r = 0; r < s->wide.n_prims(); ++r) {
-                    const float* q = &s->wide.prims[12 * (size_t)r];
                     float mn[3], mx[3];
-                    if (float_to_bits(q[3]) == 0u) {
-                        for (int a = 0; a < 3; ++a) {
-                            mn[a] = q[a] < q[4 + a] ? (q[a] < q[8 + a] ? q[a] : q[8 + a]) : (q[4 + a] < q[8 + a] ? q[4 + a] : q[8 + a]);
-                            mx[a] = q[a] > q[4 + a] ? (q[a] > q[8 + a] ? q[a] : q[8 + a]) : (q[4 + a] > q[8 + a] ? q[4 + a] : q[8 + a]);
-                        }
-                    } else {
-                        for (int a = 0; a < 3; ++a) { mn[a] = q[a] - q[4]; mx[a] = q[a] + q[4]; }
-                    }
+                    record_box(&s->wide.prims[12 * (size_t)r], mn, mx);
                     bool overlap = true;
                     for (int a = 0; a < 3; ++a) overlap = overlap && mn[a] <= c[a] + c[3] && mx[a] >= c[a] - c[3];
                     if (!overlap) continue;
@@ -283,16 +292,27 @@ int upload_scene(rt_scene* s) {
                     uint32_t rec = r;
                     for (int k = 0; k < RT_HOT; ++k)   // insertion into the descending top list
                         if (area > best_area[k]) {
-                            const float ta = best_area[k]; const uint32_t tr = hot[RT_HOT * li + k];
-                            best_area[k] = area; hot[RT_HOT * li + k] = rec;
+                            const float ta = best_area[k]; const uint32_t tr = best_rec[k];
+                            best_area[k] = area; best_rec[k] = rec;
                             area = ta; rec = tr;
                         }
                 }
+                for (int k = 0; k < RT_HOT; ++k) {
+                    if (best_rec[k] == RT_W_NO_REC) continue;
+                    const float* q = &s->wide.prims[12 * (size_t)best_rec[k]];
+                    HotRec& hr = s->hot_table.rec[li][k];
+                    hr.rec = best_rec[k];
+                    hr.kind = float_to_bits(q[3]) == 0u ? 0u : 1u;
+                    for (int a = 0; a < 3; ++a) hr.a[a] = q[a];
+                    if (hr.kind == 0u) {
+                        for (int a = 0; a < 3; ++a) { hr.e1[a] = q[4 + a] - q[a]; hr.e2[a] = q[8 + a] - q[a]; }   // sub(p2, p1), sub(p3, p1)
+                    } else {
+                        hr.e1[0] = q[4];                                                                         // radius
+                    }
+                    record_box(q, hr.mn, hr.mx);
+                }
             }
         }
-        if ((rc = s->d_hot.ensure(hot.size()))) return rc;
-        HIP_TRY(hipMemcpy(s->d_hot.p, hot.data(), hot.size() * 4, hipMemcpyHostToDevice));
-        d.hot = s->d_hot.p;
     }
     d.n_wnodes = (s->wide.ok && s->opt_wide) ? s->wide.n_nodes() : 0u;
     d.refill_min = s->opt_refill_min; d.phase_bias = s->opt_phase_bias;
@@ -502,13 +522,13 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
                     begin_timing(s, stream, hemi ? 0 : (persist ? 3 : 1), &ev);
                     if (persist) {
                         const bool root = s->opt_root_in_light != 0;
-                        if (s->opt_stats) { if (root) hipLaunchKernelGGL((k_light<true, 4, true>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
-                                            else hipLaunchKernelGGL((k_light<true, 4, false>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level); }
-                        else if (root) hipLaunchKernelGGL((k_light<false, 4, true>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
-                        else if (s->opt_light_waves >= 8) hipLaunchKernelGGL((k_light<false, 8, false>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
-                        else if (s->opt_light_waves >= 6) hipLaunchKernelGGL((k_light<false, 6, false>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
-                        else if (s->opt_light_waves >= 5) hipLaunchKernelGGL((k_light<false, 5, false>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
-                        else hipLaunchKernelGGL((k_light<false, 4, false>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                        if (s->opt_stats) { if (root) hipLaunchKernelGGL((k_light<true, 4, true>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level, s->hot_table);
+                                            else hipLaunchKernelGGL((k_light<true, 4, false>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level, s->hot_table); }
+                        else if (root) hipLaunchKernelGGL((k_light<false, 4, true>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level, s->hot_table);
+                        else if (s->opt_light_waves >= 8) hipLaunchKernelGGL((k_light<false, 8, false>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level, s->hot_table);
+                        else if (s->opt_light_waves >= 6) hipLaunchKernelGGL((k_light<false, 6, false>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level, s->hot_table);
+                        else if (s->opt_light_waves >= 5) hipLaunchKernelGGL((k_light<false, 5, false>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level, s->hot_table);
+                        else hipLaunchKernelGGL((k_light<false, 4, false>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level, s->hot_table);
                         end_timing(s, stream, ev);
                         begin_timing(s, stream, 2, &ev);
                         if (s->opt_stats) hipLaunchKernelGGL(k_binary<true>, dim3(64), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
@@ -637,7 +657,7 @@ void rt_scene_destroy(rt_scene* s) {
     if (!s) return;
     if (s->uploaded) (void)hipDeviceSynchronize();
     s->d_nodes.release(); s->d_tris.release(); s->d_tri_nrm.release(); s->d_sph.release(); s->d_mats.release();
-    s->d_sph_aux.release(); s->d_lights.release(); s->d_ovf.release(); s->d_wnodes.release(); s->d_wprims.release(); s->d_wrec.release(); s->d_hot.release();
+    s->d_sph_aux.release(); s->d_lights.release(); s->d_ovf.release(); s->d_wnodes.release(); s->d_wprims.release(); s->d_wrec.release();
     s->w_counts.release(); s->w_hit_id.release(); s->w_blist.release(); s->w_hit_t.release();
     for (int q = 0; q < 2; ++q) { s->w_ray_o[q].release(); s->w_ray_d[q].release(); }
     s->w_vP.release(); s->w_vN.release(); s->w_vS.release(); s->w_contrib.release(); s->w_direct.release(); s->w_stackA.release(); s->w_stackB.release();

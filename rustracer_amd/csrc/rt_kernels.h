@@ -34,6 +34,7 @@ namespace rt {
 #define RT_ROULETTE 0.7f         // src/raytracer.rs:11
 #define RT_INFO_BLOCKER 0x80000000u
 #define RT_HOT 2                // occluders tested in k_light before any traversal, per light
+#define RT_HOT_LIGHTS 4         // lights whose occluder cache travels in k_light's kernel arguments (further lights have none)
 #define RT_CHUNK 512u           // persistent kernels: consecutive queue entries a wave takes at a time
 
 struct DevScene {
@@ -53,10 +54,23 @@ struct DevScene {
     const float4* wprims;    // 3 x float4 per blocker primitive record (48 B), in node order
     const uint32_t* wrec;    // primitive record of each object in wprims (0xFFFFFFFF: emissive, not in the tree)
     uint32_t root_in_light;  // k_light tests the root node of the occlusion BVH (else k_trace_p starts there)
-    const uint32_t* hot;     // per light, RT_HOT records of the occlusion BVH that k_light tests first (RT_W_NO_REC = none): see k_light
     uint32_t n_wnodes;       // 0: shadow rays take the binary tree
     uint32_t refill_min;     // k_trace_p: idle lanes that trigger a refill of the wave
     uint32_t phase_bias;     // k_trace_p: node step when 4 * lanes_at_nodes >= phase_bias * lanes_at_primitives
+};
+
+// Occluder cache of k_light, passed by value as a kernel argument so that its fields arrive through scalar loads:
+// per light the RT_HOT largest blockers next to it, with everything that does not depend on the ray worked out on the host by
+// the same single-precision operations the kernels would use (edges, own box).
+struct HotRec {
+    uint32_t kind;            // 0 triangle, 1 sphere, 2 none
+    uint32_t rec;             // its record in the occlusion BVH (a ray that starts on it is not tested against it twice)
+    float a[3];               // p1 / centre
+    float e1[3], e2[3];       // triangle edges / (radius, -, -), -
+    float mn[3], mx[3];       // own box (Bounded, objects.rs:293-316)
+};
+struct HotTable {
+    HotRec rec[RT_HOT_LIGHTS][RT_HOT];
 };
 
 struct TravStats {
@@ -159,10 +173,13 @@ __device__ __forceinline__ bool slab(const BoxRay& r, float mnx, float mny, floa
     return !miss && (ray_max > 0.0f);
 }
 
-// Object::intersect, triangle arm (src/scene/objects.rs:38-57).
+// Object::intersect, triangle arm (src/scene/objects.rs:38-57).  The edges e1 = p2 - p1, e2 = p3 - p1 are the first two operations
+// of the reference's function; hit_triangle_e takes them ready-made (the occluder cache computes them once, on the host).
+__device__ __forceinline__ bool hit_triangle_e(vec3 p1, vec3 e1, vec3 e2, vec3 o, vec3 d, float* t_out);
 __device__ __forceinline__ bool hit_triangle(vec3 p1, vec3 p2, vec3 p3, vec3 o, vec3 d, float* t_out) {
-    const vec3 e1 = sub(p2, p1);
-    const vec3 e2 = sub(p3, p1);
+    return hit_triangle_e(p1, sub(p2, p1), sub(p3, p1), o, d, t_out);
+}
+__device__ __forceinline__ bool hit_triangle_e(vec3 p1, vec3 e1, vec3 e2, vec3 o, vec3 d, float* t_out) {
     const vec3 s = sub(o, p1);
     const vec3 s1 = cross3(d, e2);
     const vec3 s2 = cross3(s, e1);
@@ -903,7 +920,7 @@ __device__ __forceinline__ size_t ls_slot(uint32_t e, uint32_t j, uint32_t nlL) 
     return (size_t)(e >> 6) * (64u * (size_t)nlL) + (size_t)j * 64u + (e & 63u);
 }
 template <bool STATS, int WAVES, bool ROOT>   // WAVES: waves per SIMD the register budget is sized for; ROOT: test the BVH root here
-__global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx pc, uint32_t level) {
+__global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx pc, uint32_t level, HotTable hot) {
     TravStats tst = {0, 0, 0, 0, 0};
     const uint32_t n = pc.vcounts[level], n_round = (n + 63u) & ~63u;
     const uint32_t nlL = pc.nlL, L = pc.P.light_samples;
@@ -943,9 +960,8 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
           // Occluder cache: is_occluded is "some non-emissive object blocks", whichever is found first, so the large occluders next
           // to this light (chosen at scene build: a ceiling the lamp pokes through blocks 4 of 5 samples of the Cornell lamp) are
           // tested here, by every lane and from registers, before any ray is queued for traversal.  Same exact tests as at a leaf.
-          uint32_t hot_rec[RT_HOT];
-#pragma unroll
-          for (int h = 0; h < RT_HOT; ++h) hot_rec[h] = sc.hot[RT_HOT * g + h];
+          const uint32_t hg = g < RT_HOT_LIGHTS ? g : 0u;
+          const bool has_hot = g < RT_HOT_LIGHTS;
           for (uint32_t ls = 0; ls < L; ++ls, ++j, sl += 64) {                 // for _ in 0..light_samples (raytracer.rs:269)
             const ulonglong2 jm = pc.jump[j];
             uint64_t rng = jm.x * rng0 + jm.y;
@@ -973,24 +989,18 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
             }
 #pragma unroll
             for (int h = 0; h < RT_HOT; ++h) {
-                if (hot_rec[h] != RT_W_NO_REC && hot_rec[h] != self_rec && !binary && !blocked) {      // (uniform but for the last three)
-                    // the record is fetched here, through the scalar cache, every sample: kept in registers across the loop
-                    // it costs more registers than this kernel has
-                    const float4* hp = sc.wprims + 3 * (size_t)hot_rec[h];
-                    asm volatile("" : "+s"(hp));
-                    const float4 hA = hp[0], hB = hp[1], hC = hp[2];
+                const HotRec& hr = hot.rec[hg][h];      // kernel argument: scalar loads, operands straight from SGPRs
+                if (has_hot && hr.kind != 2u && hr.rec != self_rec && !binary && !blocked) {      // (uniform but for the last three)
                     float t = 0.0f, tn;
                     bool ok;
-                    if (__float_as_uint(hA.w) == 0u) {
+                    if (hr.kind == 0u) {
                         if (STATS) tst.tris++;
-                        ok = hit_triangle(xyz(hA), xyz(hB), xyz(hC), p, wi, &t) && t > 0.0f && t < d_s &&
-                             slab(br, lo3(hA.x, hB.x, hC.x), lo3(hA.y, hB.y, hC.y), lo3(hA.z, hB.z, hC.z), hi3(hA.x, hB.x, hC.x), hi3(hA.y, hB.y, hC.y),
-                                  hi3(hA.z, hB.z, hC.z), &tn);
+                        ok = hit_triangle_e(mk(hr.a[0], hr.a[1], hr.a[2]), mk(hr.e1[0], hr.e1[1], hr.e1[2]), mk(hr.e2[0], hr.e2[1], hr.e2[2]), p, wi, &t) &&
+                             t > 0.0f && t < d_s && slab(br, hr.mn[0], hr.mn[1], hr.mn[2], hr.mx[0], hr.mx[1], hr.mx[2], &tn);
                     } else {
                         if (STATS) tst.sphs++;
-                        const float r = hB.x;
-                        ok = hit_sphere(make_float4(hA.x, hA.y, hA.z, r), p, wi, &t) && t > 0.0f && t < d_s &&
-                             slab(br, hA.x - r, hA.y - r, hA.z - r, hA.x + r, hA.y + r, hA.z + r, &tn);
+                        ok = hit_sphere(make_float4(hr.a[0], hr.a[1], hr.a[2], hr.e1[0]), p, wi, &t) && t > 0.0f && t < d_s &&
+                             slab(br, hr.mn[0], hr.mn[1], hr.mn[2], hr.mx[0], hr.mx[1], hr.mx[2], &tn);
                     }
                     blocked = ok;
                 }
