@@ -179,17 +179,22 @@ __device__ __forceinline__ bool hit_triangle_e(vec3 p1, vec3 e1, vec3 e2, vec3 o
 __device__ __forceinline__ bool hit_triangle(vec3 p1, vec3 p2, vec3 p3, vec3 o, vec3 d, float* t_out) {
     return hit_triangle_e(p1, sub(p2, p1), sub(p3, p1), o, d, t_out);
 }
-__device__ __forceinline__ bool hit_triangle_e(vec3 p1, vec3 e1, vec3 e2, vec3 o, vec3 d, float* t_out) {
-    const vec3 s = sub(o, p1);
+// ... and hit_triangle_o the part that depends on the ray origin only: s = o - p1, s2 = s x e1, tnum = s2 . e2 (a path vertex
+// sends many rays from one origin).  Same operations on the same values, in the reference's order.
+__device__ __forceinline__ bool hit_triangle_o(vec3 e1, vec3 e2, vec3 s, vec3 s2, float tnum, vec3 d, float* t_out) {
     const vec3 s1 = cross3(d, e2);
-    const vec3 s2 = cross3(s, e1);
     const float scalar = 1.0f / dot3(s1, e1);
-    const float t = dot3(s2, e2) * scalar;
+    const float t = tnum * scalar;
     const float b1 = dot3(s1, s) * scalar;
     const float b2 = dot3(s2, d) * scalar;
     if (b1 < 0.0f || b2 < 0.0f || b1 > 1.0f || b2 > 1.0f || b1 + b2 > 1.0f + RT_EPS || t < RT_EPS) return false;
     *t_out = t;
     return true;
+}
+__device__ __forceinline__ bool hit_triangle_e(vec3 p1, vec3 e1, vec3 e2, vec3 o, vec3 d, float* t_out) {
+    const vec3 s = sub(o, p1);
+    const vec3 s2 = cross3(s, e1);
+    return hit_triangle_o(e1, e2, s, s2, dot3(s2, e2), d, t_out);
 }
 // Object::intersect, sphere arm (src/scene/objects.rs:58-76): the nearer root, negative included.
 __device__ __forceinline__ bool hit_sphere(float4 cr, vec3 o, vec3 d, float* t_out) {
@@ -962,6 +967,16 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
           // tested here, by every lane and from registers, before any ray is queued for traversal.  Same exact tests as at a leaf.
           const uint32_t hg = g < RT_HOT_LIGHTS ? g : 0u;
           const bool has_hot = g < RT_HOT_LIGHTS;
+          // the part of the cached triangles' test that depends on the vertex only (hit_triangle_o)
+          vec3 hot_s[RT_HOT], hot_s2[RT_HOT];
+          float hot_tn[RT_HOT];
+#pragma unroll
+          for (int h = 0; h < RT_HOT; ++h) {
+              const HotRec& hr = hot.rec[hg][h];
+              hot_s[h] = sub(p, mk(hr.a[0], hr.a[1], hr.a[2]));
+              hot_s2[h] = cross3(hot_s[h], mk(hr.e1[0], hr.e1[1], hr.e1[2]));
+              hot_tn[h] = dot3(hot_s2[h], mk(hr.e2[0], hr.e2[1], hr.e2[2]));
+          }
           for (uint32_t ls = 0; ls < L; ++ls, ++j, sl += 64) {                 // for _ in 0..light_samples (raytracer.rs:269)
             const ulonglong2 jm = pc.jump[j];
             uint64_t rng = jm.x * rng0 + jm.y;
@@ -995,7 +1010,7 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
                     bool ok;
                     if (hr.kind == 0u) {
                         if (STATS) tst.tris++;
-                        ok = hit_triangle_e(mk(hr.a[0], hr.a[1], hr.a[2]), mk(hr.e1[0], hr.e1[1], hr.e1[2]), mk(hr.e2[0], hr.e2[1], hr.e2[2]), p, wi, &t) &&
+                        ok = hit_triangle_o(mk(hr.e1[0], hr.e1[1], hr.e1[2]), mk(hr.e2[0], hr.e2[1], hr.e2[2]), hot_s[h], hot_s2[h], hot_tn[h], wi, &t) &&
                              t > 0.0f && t < d_s && slab(br, hr.mn[0], hr.mn[1], hr.mn[2], hr.mx[0], hr.mx[1], hr.mx[2], &tn);
                     } else {
                         if (STATS) tst.sphs++;
