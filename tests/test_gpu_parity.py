@@ -271,6 +271,31 @@ def test_occluder_cache_and_scheduling_switches_do_not_change_a_pixel(gpu):
     assert 0 < c_hot["trace_steps"][5] < c_cold["trace_steps"][5]      # rays handed to k_trace_p: fewer with the cache
 
 
+def test_occluder_cache_with_a_sphere_next_to_the_lamp(gpu):
+    """The cache's sphere arm: a diffuse ball hangs right under the lamp of the sphere-on-plane scene (their boxes overlap, so it is
+    the lamp's cached occluder) and shadows most of the plane; images with the cache on and off equal the oracle's."""
+    from oracle import binding as ob
+    import rustracer_amd as ra
+    e = ra.Scene._named("sphere_on_plane", None).export()
+    sph = np.concatenate([e["sph"], np.array([[0.5, 14.0, -57.0, 5.0]], np.float32)])
+    sph_mat = np.concatenate([e["sph_mat"], e["sph_mat"][-1:]])                      # the grey of the other ball
+    args = (e["tri_pos"], e["tri_nrm"], e["tri_mat"], sph, sph_mat, e["mats"])
+    osc = ob.OracleScene.raw(*args)
+    op = oracle_params(width=64, height=48, spp=4, light_samples=8, bounces=3, seed=11)
+    ref = osc.render(op)
+    for hot in (1, 0):
+        gsc = ra.Scene.from_arrays(*args)
+        gsc.set_option("hot", hot)
+        gsc.set_option("stats", 1)
+        got, cnt = gpu_render(gsc, to_rt_params(op))
+        assert np.array_equal(got, ref["rgba"]), "hot=%d" % hot
+        assert cnt["rays_shadow"] == ref["occluded_calls"]
+        traced = cnt["trace_steps"][5]
+        if hot:
+            traced_hot = traced
+    assert traced_hot < traced                                                       # the cached ball settles rays before traversal
+
+
 def test_axis_aligned_shadow_rays_take_the_binary_tree(gpu):
     """Light sampling almost never produces a direction with a zero component, so Scene::is_occluded is driven directly:
     rays with zero, denormal and tiny direction components (the 0 * inf = NaN cases of the slab test, which leave the 8-wide
