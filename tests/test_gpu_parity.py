@@ -223,9 +223,9 @@ def _two_light_scene():
 
 
 @pytest.mark.parametrize("w,h,spp,L,b,cam", [(72, 56, 4, 3, 6, (0.0, 0.0, 0.0)), (64, 64, 3, 5, 4, (2.0, -4.0, -6.0)), (40, 40, 2, 32, 3, (0.0, 0.0, 0.0)),
-                                             (33, 47, 2, 70, 2, (0.0, 0.0, 0.0))])
+                                             (33, 47, 2, 70, 2, (0.0, 0.0, 0.0)), (24, 20, 1, 300, 2, (0.0, 0.0, 0.0))])
 def test_two_lights_odd_sample_counts_and_moved_camera(gpu, w, h, spp, L, b, cam):
-    """lights x light_samples = 6, 10, 64, 140 slots per vertex (not powers of two, more than a wave), camera off the origin
+    """lights x light_samples = 6, 10, 64, 140, 600 slots per vertex (not powers of two, more than a wave), camera off the origin
     (Raytracer::move_camera, raytracer.rs:477-481): image and ray counts identical to the oracle."""
     osc, gsc = _two_light_scene()
     assert list(gsc.light_indexes()) == [10, 13]
