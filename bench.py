@@ -51,6 +51,9 @@ def parse():
 
 def main():
     a = parse()
+    if os.environ.get("RT_BENCH_WATCHDOG"):   # seconds: dump every thread's stack and exit if the run is still going (rehearsals)
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["RT_BENCH_WATCHDOG"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -64,12 +67,18 @@ def main():
     from rustracer_amd._lib import RT_MODE_FULL, check, lib
     from rustracer_amd.raytracer import Config, RenderConfig, make_params
 
-    torch.cuda.set_device(local_rank)
-    check(lib().rt_init(local_rank))
-    dev = torch.device("cuda", local_rank)
+    # RT_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share devices; not a measurement)
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    check(lib().rt_init(dev_index))
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     # ---- scene (replicated on every rank; the BVH is built on the host) ----
     dragon_obj = os.path.join(ROOT, "obj", "dragon.obj")
@@ -237,7 +246,7 @@ def main():
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[3]: dragon GI, %dx%d, %d spp, %d light samples, depth %d, 32x32 screen tiles over %d GPU(s)%s"
-                   % (a.width, a.height, a.spp, a.light_samples, a.bounces, world, " + RCCL all_gather" if world > 1 else ""),
+                   % (a.width, a.height, a.spp, a.light_samples, a.bounces, world, (" + RCCL all_gather" if backend == "nccl" else " + %s all_gather (rehearsal: ranks share devices)" % backend) if world > 1 else ""),
                    "mesh": "%s, %d triangles" % (mesh_label, n_tri - 10), "seed": a.seed, "scene_build_s": round(scene_s, 2)},
         "samples_per_s": round(samples * a.steps / elapsed, 1),
         "rays_per_step": int(rays_per_step), "rays_closest_per_step": int(rays_closest), "rays_shadow_per_step": int(rays_shadow),

@@ -78,8 +78,11 @@ def gather_frame(frame, width, height, tile_w, tile_h, rank, world, group=None):
     gathered = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
     if dist.get_backend(group) == "nccl":                                      # RCCL: one collective, w*h*C bytes in total
         dist.all_gather_into_tensor(gathered, mine.contiguous(), group=group)
-    else:                                                                      # gloo (CPU tests) has no all_gather_into_tensor
-        dist.all_gather([gathered[r] for r in range(world)], mine.contiguous(), group=group)
+    else:                                                                      # gloo (CPU tests, rehearsals): host tensors, list form
+        parts = [torch.empty(mine.shape, dtype=mine.dtype) for _ in range(world)]
+        dist.all_gather(parts, mine.contiguous().cpu(), group=group)
+        for r in range(world):
+            gathered[r].copy_(parts[r])
     out = torch.zeros_like(flat)
     for r in range(world):
         _, _, dst, sel = _device_index(width, height, tile_w, tile_h, r, world, frame.device)
