@@ -550,3 +550,34 @@ def test_baseline_configs_at_full_resolution(scenes, name, w, h, spp, L, b, est,
         assert np.array_equal(a, r), "tile %d: %d bytes differ" % (t, int((a != r).sum()))
     if stride == 1:
         assert cnt["rays_closest"] == ref["intersect_calls"] and cnt["rays_shadow"] == ref["occluded_calls"]
+
+
+def test_degenerate_scenes_and_frames(gpu):
+    """Empty object list, a lamp alone (no blocker: no occlusion BVH), one wall under a lamp, a 1x1 frame and a frame whose size is no
+    multiple of the screen tile: images and ray counts equal the oracle's."""
+    from oracle import binding as ob
+    import rustracer_amd as ra
+    mats = np.zeros((2, 8), np.uint32)
+    mats[0, 1:4] = np.array([0.78, 0.78, 0.78], np.float32).view(np.uint32)          # grey diffuse
+    mats[1, 4:7] = np.array([1, 1, 1], np.float32).view(np.uint32)                   # lamp
+    none3, none4 = np.zeros((0, 9), np.float32), np.zeros((0, 4), np.float32)
+    lamp = np.array([[0.0, 6.0, -30.0, 3.0]], np.float32)
+    wall = np.array([[-30, -8, -10, 30, -8, -10, 0, -8, -70]], np.float32)
+    wall_n = np.array([[0, 1, 0] * 3], np.float32)
+    cases = [
+        (none3, none3, [], none4, [], mats),                                          # nothing at all
+        (none3, none3, [], lamp, [1], mats),                                          # the lamp alone
+        (wall, wall_n, [0], lamp, [1], mats),                                         # one triangle + lamp
+        (wall, wall_n, [0], none4, [], mats),                                         # one triangle, no light
+    ]
+    for k, args in enumerate(cases):
+        osc, gsc = ob.OracleScene.raw(*args), ra.Scene.from_arrays(*args)
+        for (w, h, spp, L, b) in ((1, 1, 3, 2, 4), (45, 37, 2, 3, 3)):
+            op = oracle_params(width=w, height=h, spp=spp, light_samples=L, bounces=b, seed=5)
+            ref = osc.render(op)
+            got, cnt = gpu_render(gsc, to_rt_params(op))
+            assert np.array_equal(got, ref["rgba"]), (k, w, h)
+            assert cnt["rays_closest"] == ref["intersect_calls"] and cnt["rays_shadow"] == ref["occluded_calls"], (k, w, h)
+            oi, ot, _ = osc.cast_primary(op)
+            gi, gt = gpu_cast(gsc, to_rt_params(op))
+            assert np.array_equal(gi, oi) and np.array_equal(gt.view(np.uint32), ot.view(np.uint32)), (k, w, h)
