@@ -581,3 +581,33 @@ def test_degenerate_scenes_and_frames(gpu):
             oi, ot, _ = osc.cast_primary(op)
             gi, gt = gpu_cast(gsc, to_rt_params(op))
             assert np.array_equal(gi, oi) and np.array_equal(gt.view(np.uint32), ot.view(np.uint32)), (k, w, h)
+
+
+def test_coincident_and_degenerate_triangles(gpu):
+    """2000 copies of one triangle (every closest hit is a 2000-way tie in t, settled by the reference's traversal order; the builder
+    falls back to halving), zero-area triangles and slivers, under a lamp: ids, distances, images and ray counts equal the oracle's."""
+    from oracle import binding as ob
+    import rustracer_amd as ra
+    rng = np.random.default_rng(12)
+    one = np.array([-9, -6, -30, 9, -6, -30, 0, 8, -34], np.float32)
+    tri = np.tile(one, (2000, 1))
+    zero_area = np.tile(np.array([1, 1, -20, 1, 1, -20, 2, 2, -21], np.float32), (50, 1))
+    p = rng.uniform([-15, -10, -50], [15, 10, -15], (300, 3)).astype(np.float32)
+    sliver = np.concatenate([p, p + np.float32(1e-4) * rng.normal(size=(300, 3)).astype(np.float32), p + rng.normal(size=(300, 3)).astype(np.float32)], axis=1)
+    floor = np.array([[-40, -12, 0, 40, -12, 0, 0, -12, -90]], np.float32)
+    pos = np.concatenate([tri, zero_area, sliver, floor]).astype(np.float32)
+    nrm = np.tile(np.array([0, 0, 1] * 3, np.float32), (pos.shape[0], 1))
+    mats = np.zeros((2, 8), np.uint32)
+    mats[0, 1:4] = np.array([0.7, 0.6, 0.5], np.float32).view(np.uint32)
+    mats[1, 4:7] = np.array([1, 1, 1], np.float32).view(np.uint32)
+    args = (pos, nrm, np.zeros(pos.shape[0], np.uint32), np.array([[3.0, 14.0, -25.0, 4.0]], np.float32), [1], mats)
+    osc, gsc = ob.OracleScene.raw(*args), ra.Scene.from_arrays(*args)
+    op = oracle_params(width=96, height=80, spp=2, light_samples=4, bounces=4, seed=3)
+    oi, ot, _ = osc.cast_primary(op)
+    gi, gt = gpu_cast(gsc, to_rt_params(op))
+    assert np.array_equal(gi, oi) and np.array_equal(gt.view(np.uint32), ot.view(np.uint32))
+    assert ((gi < 2000).sum()) > 500                                   # the stack of copies is in view
+    ref = osc.render(op)
+    got, cnt = gpu_render(gsc, to_rt_params(op))
+    assert np.array_equal(got, ref["rgba"])
+    assert cnt["rays_closest"] == ref["intersect_calls"] and cnt["rays_shadow"] == ref["occluded_calls"]
