@@ -611,3 +611,25 @@ def test_coincident_and_degenerate_triangles(gpu):
     got, cnt = gpu_render(gsc, to_rt_params(op))
     assert np.array_equal(got, ref["rgba"])
     assert cnt["rays_closest"] == ref["intersect_calls"] and cnt["rays_shadow"] == ref["occluded_calls"]
+
+
+@pytest.mark.parametrize("scale_by", [3.0e18, 2.0e8, 1.0e-18])
+def test_scene_at_extreme_scale(gpu, scale_by):
+    """The specular scene blown up past the 8-wide tree's coordinate range (is_occluded falls back to the binary tree; products in
+    the triangle test overflow to inf and NaN) and shrunk towards the denormals: same IEEE operations, same ids, distances and image."""
+    from oracle import binding as ob
+    import rustracer_amd as ra
+    e = ra.Scene.new_specular().export()
+    s = np.float32(scale_by)
+    sph = e["sph"] * s
+    args = (e["tri_pos"] * s, e["tri_nrm"], e["tri_mat"], sph, e["sph_mat"], e["mats"])
+    osc, gsc = ob.OracleScene.raw(*args), ra.Scene.from_arrays(*args)
+    assert (gsc.info.n_wide_nodes == 0) == (scale_by > 1.0e18)
+    op = oracle_params(width=72, height=64, spp=2, light_samples=3, bounces=4, seed=21)
+    oi, ot, _ = osc.cast_primary(op)
+    gi, gt = gpu_cast(gsc, to_rt_params(op))
+    assert np.array_equal(gi, oi) and np.array_equal(gt.view(np.uint32), ot.view(np.uint32))
+    ref = osc.render(op)
+    got, cnt = gpu_render(gsc, to_rt_params(op))
+    assert cnt["rays_closest"] == ref["intersect_calls"] and cnt["rays_shadow"] == ref["occluded_calls"]
+    assert np.array_equal(got, ref["rgba"]), "%d bytes differ" % int((got != ref["rgba"]).sum())
