@@ -85,7 +85,9 @@ typedef struct rt_counters {
 typedef struct rt_scene rt_scene;
 
 const char* rt_last_error(void);
-/* Binds the calling process to one GPU (hipSetDevice).  One process per GPU. */
+/* Chooses the GPU of this process (one process per GPU).  hipSetDevice binds only the calling host thread, so the library
+ * records the device here and in every scene created afterwards, and every entry point selects it again on the thread
+ * that calls it: rt_render may be called from a thread other than the one that called rt_init (src/raytracer.rs:527). */
 int rt_init(int device);
 
 /* Scene::new (src/scene/mod.rs:82-106): objects = triangles then spheres, lights = objects with
@@ -112,7 +114,9 @@ int rt_scene_wide_bvh(const rt_scene* scene, uint32_t* node_words, float* prim_r
 /* do_render / debug_render (src/raytracer.rs:167, 353) for the pixels of one shard.
  * rgba: width*height*4 bytes, row-major, top row first, alpha 255 (SharedPixelBuffer,
  * src/raytracer.rs:22-51); only owned pixels are written.
- * rt_render: rgba is host memory; blocks; progress (0..100, src/raytracer.rs:79) and interrupt may be NULL.
+ * rt_render: rgba is host memory; blocks; progress (0..100, src/raytracer.rs:79) and interrupt may be NULL.  *interrupt is
+ * polled between passes and, inside a pass, between bounce levels (the reference polls per pixel, src/raytracer.rs:184-204):
+ * a render stops within one bounce level of one pass of raising it.
  * rt_render_device: rgba is device memory; work is enqueued on `stream` (hipStream_t, may be NULL)
  * and the call returns without synchronising. */
 int rt_render(rt_scene* scene, const rt_render_params* params, uint8_t* rgba,
@@ -160,7 +164,8 @@ int rt_scene_export(const rt_scene* scene, float* tri_pos, float* tri_nrm, uint3
 int rt_make_dragon_standin(uint32_t nu, uint32_t nv, float* vpos, float* vnrm, uint32_t* faces);
 
 /* ---- debug probes used by the parity tests (device evaluation of the shared arithmetic) ---- */
-/* op: 0 sin, 1 cos, 2 acos, 3 pow(x, y[i]), 4 to_color -> out as float */
+/* op: 0 sin, 1 cos, 2 acos (double-precision definitions), 3 pow(x, y[i]), 4 to_color -> out as float,
+ * 5 sin, 6 cos, 7 acos as the samplers evaluate them (single precision, rt_math.h sincos_s / acos_s) */
 int rt_debug_math(uint32_t op, const float* x, const float* y, uint32_t n, float* out);
 int rt_debug_rng(uint64_t seed, uint32_t pixel_index, uint32_t sample, uint32_t n, float* out);
 

@@ -64,6 +64,8 @@ def lib():
         for name in ("orc_math_sin", "orc_math_cos", "orc_math_acos"):
             getattr(L, name).argtypes = [C.c_float]
             getattr(L, name).restype = C.c_float
+        L.orc_math_batch.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_math_batch.restype = None
         L.orc_math_pow.argtypes = [C.c_float, C.c_float]
         L.orc_math_pow.restype = C.c_float
         L.orc_random_sphere.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]

@@ -17,8 +17,11 @@
 //     geo.rs:102-103,136-137).  Here every (pixel, sample) owns a stream seeded from
 //     hash(seed, pixel_index, sample); the generator and float conversion are unchanged.
 //   * sin/cos/acos/powf: the reference calls the platform libm through f32::sin etc.  Here they
-//     are fixed double-precision polynomial evaluations rounded once to f32 (orc_sinf ...), so
-//     that a CPU and a GPU evaluating the same formula agree bit for bit.  tests/ bound their
+//     are fixed sequences of IEEE operations, so that a CPU and a GPU evaluating the same formula
+//     agree bit for bit: the samplers (geo.rs:101-145) use single-precision fused-multiply-add
+//     kernels (orc_sincos_s, orc_acos_s: < 0.9 ulp from the exact value on every float of their
+//     domains, tools/mathcheck.cpp), ScreenParams and the tone map use double-precision polynomial
+//     evaluations rounded once to f32 (orc_sinf, orc_powf: <= 0.5001 ulp).  tests/ bound their
 //     distance to libm in ulps.
 //
 // Build: oracle/Makefile  (g++ -O2 -ffp-contract=off, no fast-math).
@@ -115,6 +118,52 @@ inline float orc_acosf(float xf) {
     double w = s + s * asin_R(z);  // asin(sqrt(z))
     if (x > 0.0) return (float)(2.0 * w);
     return (float)(PI_D - 2.0 * w);
+}
+
+// f32::sin / f32::cos / f32::acos as the samplers call them (geo.rs:106-107, 138-143): the build's single-precision
+// definition (see header; rustracer_amd/csrc/rt_math.h holds the device's statement of the same operations).
+// pi/2 = H + M + L with M cut to 21 bits, so that k*M is exact for the k <= 4 that occur (0 <= x <= 2 pi).
+const float S_PIO2_H = 1.57079637050628662109375f, S_PIO2_M = -4.3711395392165286466e-08f, S_PIO2_L = 5.3903029534742383927e-15f;
+inline void orc_sincos_s(float x, float* sf, float* cf) {
+    float k = std::rint(x * 0.636619746685028076171875f);   // round to nearest, ties to even
+    float r1 = std::fma(k, -S_PIO2_H, x);                    // exact
+    float p = k * S_PIO2_M;                                  // exact
+    float r = r1 - p;
+    float lo = (r1 - r) - p;                                 // the rounding error of r, exactly
+    lo = std::fma(k, -S_PIO2_L, lo);
+    float z = r * r;
+    float ps = std::fma(-0.00019508754485286772f, z, 0.008332112804055214f);
+    ps = std::fma(ps, z, -0.16666653752326965f);
+    float s = r + std::fma(r * z, ps, lo);                   // sin(r + lo)
+    float pc = std::fma(2.4425688025075942e-05f, z, -0.0013887251261621714f);
+    pc = std::fma(pc, z, 0.04166664555668831f);
+    float w = std::fma(-0.5f, z, 1.0f);
+    float e = std::fma(-0.5f, z, 1.0f - w);                  // what rounding w lost
+    float t = std::fma(z * z, pc, e);
+    t = std::fma(-r, lo, t);
+    float c = w + t;                                         // cos(r + lo)
+    switch ((int)k & 3) {
+        case 0: *sf = s; *cf = c; break;
+        case 1: *sf = c; *cf = -s; break;
+        case 2: *sf = -s; *cf = -c; break;
+        default: *sf = -c; *cf = s; break;
+    }
+}
+inline float orc_acos_s(float u) {
+    float a = u < 0.0f ? -u : u;
+    bool small = a <= 0.5f;
+    float z = small ? u * u : (1.0f - a) * 0.5f;
+    float p = std::fma(0.04216630756855011f, z, 0.024179520085453987f);
+    p = std::fma(p, z, 0.04547037556767464f);
+    p = std::fma(p, z, 0.07495297491550446f);
+    p = std::fma(p, z, 0.16666752099990845f);
+    float R = z * p;                                         // asin(x) = x + x R(x^2)
+    if (small) return S_PIO2_H - (u - std::fma(-u, R, S_PIO2_M));
+    float sq = std::sqrt(z);
+    float c = sq > 0.0f ? std::fma(-sq, sq, z) / (sq + sq) : 0.0f;   // sqrt(z) = sq + c
+    float w = std::fma(sq, R, c);
+    if (u > 0.0f) return 2.0f * (sq + w);
+    return 2.0f * S_PIO2_H - 2.0f * (sq + (w - S_PIO2_M));
 }
 
 // powf for the tone map (common.rs:57): base in [0,1], exponent 1/2.2.  exp(y*log(x)) in double.
@@ -254,7 +303,7 @@ inline V3 random_hemisphere(Rng* rng) {
     float sin_theta = std::sqrt(1.0f - xi1 * xi1);
     float phi = 2.0f * PI_F * xi2;
     float sin_phi, cos_phi;
-    orc_sincos(phi, &sin_phi, &cos_phi);
+    orc_sincos_s(phi, &sin_phi, &cos_phi);
     return v3(sin_theta * cos_phi, sin_theta * sin_phi, cos_theta);
 }
 // geo.rs:118-132
@@ -276,10 +325,10 @@ inline V3 random_sphere(Rng* rng) {
     float xi1 = rng_f32(rng);
     float xi2 = rng_f32(rng);
     float theta = 2.0f * PI_F * xi1;
-    float phi = orc_acosf(1.0f - 2.0f * xi2);
+    float phi = orc_acos_s(1.0f - 2.0f * xi2);
     float sp_, cp_, st_, ct_;
-    orc_sincos(phi, &sp_, &cp_);
-    orc_sincos(theta, &st_, &ct_);
+    orc_sincos_s(phi, &sp_, &cp_);
+    orc_sincos_s(theta, &st_, &ct_);
     return v3(sp_ * ct_, sp_ * st_, cp_);
 }
 
@@ -1278,6 +1327,20 @@ float orc_math_sin(float x) { return orc_sinf(x); }
 float orc_math_cos(float x) { return orc_cosf(x); }
 float orc_math_acos(float x) { return orc_acosf(x); }
 float orc_math_pow(float x, float y) { return orc_powf(x, y); }
+// op: 0 sin, 1 cos, 2 acos (double-precision definitions); 5 sin, 6 cos, 7 acos (the samplers' single-precision definitions)
+void orc_math_batch(uint32_t op, const float* x, uint32_t n, float* out) {
+    for (uint32_t i = 0; i < n; ++i) {
+        float s, c;
+        switch (op) {
+            case 0: out[i] = orc_sinf(x[i]); break;
+            case 1: out[i] = orc_cosf(x[i]); break;
+            case 2: out[i] = orc_acosf(x[i]); break;
+            case 5: orc_sincos_s(x[i], &s, &c); out[i] = s; break;
+            case 6: orc_sincos_s(x[i], &s, &c); out[i] = c; break;
+            default: out[i] = orc_acos_s(x[i]); break;
+        }
+    }
+}
 void orc_random_sphere(uint64_t seed, uint32_t pixel, uint32_t sample, float* out3) {
     Rng r = rng_for(seed, pixel, sample); V3 v = random_sphere(&r); out3[0] = v.x; out3[1] = v.y; out3[2] = v.z;
 }

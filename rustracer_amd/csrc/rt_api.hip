@@ -16,6 +16,10 @@ using namespace rt;
 namespace {
 
 thread_local std::string g_error;
+// The GPU of this process, chosen by rt_init.  hipSetDevice binds only the calling host thread, and callers render from
+// threads of their own (Raytracer::render(false) spawns one, src/raytracer.rs:527), so every entry point that touches HIP
+// selects the device again: the scene's (recorded at creation) or, for calls without a scene, the process's.
+int g_device = 0;
 
 int fail(int code, const std::string& msg) {
     g_error = msg;
@@ -26,6 +30,8 @@ int fail(int code, const std::string& msg) {
         hipError_t e_ = (expr);                                                                             \
         if (e_ != hipSuccess) return fail(RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
     } while (0)
+
+#define BIND(dev) HIP_TRY(hipSetDevice(dev))
 
 template <class T>
 struct DevBuf {
@@ -55,6 +61,7 @@ struct EventPair {
 }  // namespace
 
 struct rt_scene {
+    int device = 0;   // the GPU this scene lives on (g_device when it was created)
     HostScene host;
     FlatBVH bvh;
     WideBVH wide;
@@ -171,6 +178,7 @@ bool trees_are_well_formed(const rt_scene* s, std::string* why) {
 
 // Device half: flatten to the kernel layout and upload, on first use.
 int upload_scene(rt_scene* s) {
+    BIND(s->device);
     if (s->uploaded) return RT_OK;
     {
         std::string why;
@@ -471,6 +479,12 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
         if (!rc) break;
         (void)hipGetLastError();   // clear the out-of-memory error
         if (max_paths <= 65536) return rc;
+        // the buffers that did fit at this size would compete with the smaller retry: give the whole workspace back first
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (int q = 0; q < 2; ++q) { s->w_ray_o[q].release(); s->w_ray_d[q].release(); }
+        s->w_hit_id.release(); s->w_hit_t.release(); s->w_vP.release(); s->w_vN.release(); s->w_vS.release(); s->w_rng.release();
+        s->w_svis.release(); s->w_lray.release(); s->w_blist.release(); s->w_tmask.release(); s->w_contrib.release(); s->w_direct.release();
+        s->w_stackA.release(); s->w_stackB.release(); s->w_radiance.release(); s->w_accum.release();
     }
     if ((rc = ensure_jump(s, nlL, stream))) return rc;
 
@@ -508,6 +522,12 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
             hipLaunchKernelGGL(k_generate, dim3(grid_for(s, pc.npaths)), dim3(RT_BLOCK), 0, stream, pc);
             end_timing(s, stream, ev);
             for (uint32_t level = 0; level < levels; ++level) {
+                if (interrupt && level) {
+                    // interrupt_render() (raytracer.rs:496-498) is honoured between bounce levels: the host waits for the level it
+                    // has enqueued, so at most one level of one pass runs on after the flag is raised
+                    HIP_TRY(hipStreamSynchronize(stream));
+                    if (*interrupt) return fail(RT_ERR_INTERRUPTED, "render interrupted");
+                }
                 const uint32_t g = grid_for(s, pc.npaths);
                 begin_timing(s, stream, 0, &ev);
                 if (s->opt_stats) hipLaunchKernelGGL(k_extend<true>, dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
@@ -625,6 +645,7 @@ int rt_init(int device) {
     if (device < 0 || device >= n) return fail(RT_ERR_INVALID, "device index out of range");
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipFree(nullptr));
+    g_device = device;
     return RT_OK;
 }
 
@@ -642,6 +663,7 @@ int rt_scene_create(const float* tri_pos, const float* tri_nrm, const uint32_t* 
     for (uint32_t i = 0; i < n_mat; ++i)
         if (mats[i].bsdf > RT_BSDF_SPECULAR) return fail(RT_ERR_INVALID, "unknown bsdf");
     rt_scene* s = new rt_scene();
+    s->device = g_device;
     s->host.tri_pos.assign(tri_pos, tri_pos + 9 * (size_t)n_tri);
     s->host.tri_nrm.assign(tri_nrm, tri_nrm + 9 * (size_t)n_tri);
     s->host.tri_mat.assign(tri_mat, tri_mat + n_tri);
@@ -655,6 +677,7 @@ int rt_scene_create(const float* tri_pos, const float* tri_nrm, const uint32_t* 
 
 void rt_scene_destroy(rt_scene* s) {
     if (!s) return;
+    (void)hipSetDevice(s->device);
     if (s->uploaded) (void)hipDeviceSynchronize();
     s->d_nodes.release(); s->d_tris.release(); s->d_tri_nrm.release(); s->d_sph.release(); s->d_mats.release();
     s->d_sph_aux.release(); s->d_lights.release(); s->d_ovf.release(); s->d_wnodes.release(); s->d_wprims.release(); s->d_wrec.release();
@@ -705,6 +728,7 @@ int rt_render(rt_scene* s, const rt_render_params* params, uint8_t* rgba, volati
     if (!s || !rgba) return fail(RT_ERR_INVALID, "NULL argument");
     int rc;
     if ((rc = validate_params(params))) return rc;
+    BIND(s->device);
     const size_t bytes = (size_t)params->width * params->height * 4;
     if ((rc = s->w_frame.ensure(bytes))) return rc;
     HIP_TRY(hipMemcpy(s->w_frame.p, rgba, bytes, hipMemcpyHostToDevice));
@@ -723,6 +747,7 @@ int rt_cast_primary(rt_scene* s, const rt_render_params* params, uint32_t* ids, 
     if (!s || (!ids && !t)) return fail(RT_ERR_INVALID, "NULL argument");
     int rc;
     if ((rc = validate_params(params))) return rc;
+    BIND(s->device);
     const size_t n = (size_t)params->width * params->height;
     if (ids) { if ((rc = s->w_ids.ensure(n))) return rc; HIP_TRY(hipMemcpy(s->w_ids.p, ids, n * 4, hipMemcpyHostToDevice)); }
     if (t) { if ((rc = s->w_ts.ensure(n))) return rc; HIP_TRY(hipMemcpy(s->w_ts.p, t, n * 4, hipMemcpyHostToDevice)); }
@@ -773,6 +798,7 @@ int rt_get_counters(const rt_scene* cs, rt_counters* out) {
     rt_scene* s = const_cast<rt_scene*>(cs);
     memset(out, 0, sizeof *out);
     if (!s->uploaded) return RT_OK;
+    BIND(s->device);
     HIP_TRY(hipDeviceSynchronize());
     unsigned long long st[ST_COUNT];
     HIP_TRY(hipMemcpy(st, s->w_stats.p, sizeof st, hipMemcpyDeviceToHost));
@@ -825,6 +851,7 @@ int rt_tiles_pack(const rt_render_params* P, const void* frame_dev, void* compac
     int rc;
     if ((rc = validate_params(P))) return rc;
     if (!frame_dev || !compact_dev || bytes_per_pixel == 0 || bytes_per_pixel % 4) return fail(RT_ERR_INVALID, "bad tile copy arguments");
+    BIND(g_device);
     const uint32_t slots = rt_tiles_per_shard(P);
     const uint32_t tiles_x = (P->width + P->tile_w - 1) / P->tile_w;
     const uint64_t total = (uint64_t)slots * P->tile_w * P->tile_h;
@@ -842,6 +869,7 @@ int rt_tiles_unpack(const rt_render_params* P, uint32_t shard_index, const void*
     if ((rc = validate_params(P))) return rc;
     if (!frame_dev || !compact_dev || bytes_per_pixel == 0 || bytes_per_pixel % 4 || shard_index >= P->shard_count)
         return fail(RT_ERR_INVALID, "bad tile copy arguments");
+    BIND(g_device);
     const uint32_t slots = rt_tiles_per_shard(P);
     const uint32_t tiles_x = (P->width + P->tile_w - 1) / P->tile_w;
     const uint64_t total = (uint64_t)slots * P->tile_w * P->tile_h;
@@ -870,6 +898,7 @@ int rt_scene_new_named(const char* name, const char* obj_path, rt_scene** out) {
     if (!out || !name) return fail(RT_ERR_INVALID, "NULL argument");
     *out = nullptr;
     rt_scene* s = new rt_scene();
+    s->device = g_device;
     std::string err;
     if (!make_named_scene(name, obj_path, nullptr, nullptr, 0, nullptr, 0, &s->host, &err)) { delete s; return fail(RT_ERR_INVALID, err); }
     prepare_host(s);
@@ -883,6 +912,7 @@ int rt_scene_new_dragon_mesh(const float* vpos, const float* vnrm, uint32_t n_ve
     for (size_t i = 0; i < 3 * (size_t)n_face; ++i)
         if (faces[i] >= n_vert) return fail(RT_ERR_INVALID, "face index out of range");
     rt_scene* s = new rt_scene();
+    s->device = g_device;
     std::string err;
     if (!make_named_scene("dragon", nullptr, vpos, vnrm, n_vert, faces, n_face, &s->host, &err)) { delete s; return fail(RT_ERR_INVALID, err); }
     prepare_host(s);
@@ -912,30 +942,32 @@ int rt_make_dragon_standin(uint32_t nu, uint32_t nv, float* vpos, float* vnrm, u
 int rt_debug_math(uint32_t op, const float* x, const float* y, uint32_t n, float* out) {
     if (!x || !out || (op == 3 && !y)) return fail(RT_ERR_INVALID, "NULL argument");
     if (!n) return RT_OK;
-    float *dx = nullptr, *dy = nullptr, *dout = nullptr;
-    HIP_TRY(hipMalloc((void**)&dx, (size_t)n * 4));
-    HIP_TRY(hipMalloc((void**)&dy, (size_t)n * 4));
-    HIP_TRY(hipMalloc((void**)&dout, (size_t)n * 4));
-    HIP_TRY(hipMemcpy(dx, x, (size_t)n * 4, hipMemcpyHostToDevice));
-    if (y) HIP_TRY(hipMemcpy(dy, y, (size_t)n * 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_debug_math, dim3((n + 255) / 256), dim3(256), 0, nullptr, op, dx, dy, n, dout);
+    BIND(g_device);
+    DevBuf<float> dx, dy, dout;   // released on every path out
+    struct Guard { DevBuf<float>*a, *b, *c; ~Guard() { a->release(); b->release(); c->release(); } } guard{&dx, &dy, &dout};
+    int rc;
+    if ((rc = dx.ensure(n)) || (rc = dy.ensure(n)) || (rc = dout.ensure(n))) return rc;
+    HIP_TRY(hipMemcpy(dx.p, x, (size_t)n * 4, hipMemcpyHostToDevice));
+    if (y) HIP_TRY(hipMemcpy(dy.p, y, (size_t)n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_debug_math, dim3((n + 255) / 256), dim3(256), 0, nullptr, op, dx.p, dy.p, n, dout.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dout);
+    HIP_TRY(hipMemcpy(out, dout.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 
 int rt_debug_rng(uint64_t seed, uint32_t pixel_index, uint32_t sample, uint32_t n, float* out) {
     if (!out) return fail(RT_ERR_INVALID, "NULL argument");
     if (!n) return RT_OK;
-    float* dout = nullptr;
-    HIP_TRY(hipMalloc((void**)&dout, (size_t)n * 4));
-    hipLaunchKernelGGL(k_debug_rng, dim3(1), dim3(64), 0, nullptr, mix64(seed), pixel_index, sample, n, dout);
+    BIND(g_device);
+    DevBuf<float> dout;
+    struct Guard { DevBuf<float>* a; ~Guard() { a->release(); } } guard{&dout};
+    int rc;
+    if ((rc = dout.ensure(n))) return rc;
+    hipLaunchKernelGGL(k_debug_rng, dim3(1), dim3(64), 0, nullptr, mix64(seed), pixel_index, sample, n, dout.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(dout);
+    HIP_TRY(hipMemcpy(out, dout.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

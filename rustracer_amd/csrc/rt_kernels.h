@@ -589,7 +589,7 @@ __device__ __forceinline__ vec3 random_hemisphere(uint64_t* rng) {
     const float sin_theta = sqrtf(1.0f - xi1 * xi1);
     const float phi = 2.0f * RT_PI * xi2;
     float sin_phi, cos_phi;
-    sincos_f(phi, &sin_phi, &cos_phi);
+    sincos_s(phi, &sin_phi, &cos_phi);
     return mk(sin_theta * cos_phi, sin_theta * sin_phi, cos_theta);
 }
 __device__ __forceinline__ vec3 to_coord_space(vec3 v, vec3 n) {
@@ -609,10 +609,10 @@ __device__ __forceinline__ vec3 random_sphere(uint64_t* rng) {
     const float xi1 = next_f32(rng);
     const float xi2 = next_f32(rng);
     const float theta = 2.0f * RT_PI * xi1;
-    const float phi = acos_f(1.0f - 2.0f * xi2);
+    const float phi = acos_s(1.0f - 2.0f * xi2);
     float sp, cp, st, ct;
-    sincos_f(phi, &sp, &cp);
-    sincos_f(theta, &st, &ct);
+    sincos_s(phi, &sp, &cp);
+    sincos_s(theta, &st, &ct);
     return mk(sp * ct, sp * st, cp);
 }
 
@@ -956,6 +956,11 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
         const uint32_t self_rec = (self_is_tri || self_is_sph) ? sc.wrec[self_obj] : RT_W_NO_REC;
         const float bmnx = lo3(A.x, B.x, C.x), bmny = lo3(A.y, B.y, C.y), bmnz = lo3(A.z, B.z, C.z);
         const float bmxx = hi3(A.x, B.x, C.x), bmxy = hi3(A.y, B.y, C.y), bmxz = hi3(A.z, B.z, C.z);
+        // the part of the own triangle's test that depends on the vertex only (hit_triangle_o), once for all its light samples
+        const vec3 own_e1 = sub(xyz(B), xyz(A)), own_e2 = sub(xyz(C), xyz(A)), own_s = sub(p, xyz(A));
+        const vec3 own_s2 = cross3(own_s, own_e1);
+        const float own_tn = dot3(own_s2, own_e2);
+        uint64_t rng = rng0;                                                   // the vertex's stream: two draws per light sample, in sample order
         size_t sl = ls_slot(e0, 0, nlL);                                       // slot of sample j: + 64 per sample
         unsigned long long* row_mask = pc.tmask + (size_t)(e0 >> 6) * nlL;    // row of (this tile, sample j): + 1 per sample
         for (uint32_t g = 0, j = 0; g < pc.n_groups; ++g) {                    // for light in lights (raytracer.rs:266): per-light values stay in registers
@@ -978,8 +983,6 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
               hot_tn[h] = dot3(hot_s2[h], mk(hr.e2[0], hr.e2[1], hr.e2[2]));
           }
           for (uint32_t ls = 0; ls < L; ++ls, ++j, sl += 64) {                 // for _ in 0..light_samples (raytracer.rs:269)
-            const ulonglong2 jm = pc.jump[j];
-            uint64_t rng = jm.x * rng0 + jm.y;
             const vec3 sp = add(xyz(cr), scale(random_sphere(&rng), cr.w));      // Sphere::random_point, objects.rs:223-226
             const vec3 ps = sub(sp, p);
             const float d_s = length3(ps);
@@ -995,7 +998,7 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
                 bool ok;
                 if (self_is_tri) {
                     if (STATS) tst.tris++;
-                    ok = slab(br, bmnx, bmny, bmnz, bmxx, bmxy, bmxz, &tn) && hit_triangle(xyz(A), xyz(B), xyz(C), p, wi, &t);
+                    ok = slab(br, bmnx, bmny, bmnz, bmxx, bmxy, bmxz, &tn) && hit_triangle_o(own_e1, own_e2, own_s, own_s2, own_tn, wi, &t);
                 } else {
                     if (STATS) tst.sphs++;
                     ok = slab(br, A.x - A.w, A.y - A.w, A.z - A.w, A.x + A.w, A.y + A.w, A.z + A.w, &tn) && hit_sphere(A, p, wi, &t);
@@ -1354,6 +1357,9 @@ __global__ void k_debug_math(uint32_t op, const float* x, const float* y, uint32
         case 1: r = cos_f(x[i]); break;
         case 2: r = acos_f(x[i]); break;
         case 3: r = pow_f(x[i], y[i]); break;
+        case 5: { float c; sincos_s(x[i], &r, &c); break; }
+        case 6: { float sn; sincos_s(x[i], &sn, &r); break; }
+        case 7: r = acos_s(x[i]); break;
         default: r = (float)to_color(x[i]); break;
     }
     out[i] = r;

@@ -85,6 +85,26 @@ def test_device_math_bit_exact(gpu):
         check(lib().rt_debug_math(op, ptr(arr), None, arr.shape[0], ptr(out)))
         ref = np.array([f(C.c_float(float(v))) for v in arr], np.float32)
         assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), "op %d differs" % op
+    # the samplers' single-precision sin / cos / acos on EVERY input they can produce: theta = 2 pi xi, u = 1 - 2 xi, phi = acos(u)
+    # for all 2^23 values of xi (fastrand f32), plus the domain edges
+    xi = np.arange(1 << 23, dtype=np.float32) * np.float32(2.0 ** -23)
+    theta = (np.float32(2.0) * np.float32(np.pi)) * xi
+    u = np.concatenate([np.float32(1.0) - np.float32(2.0) * xi, np.array([-1.0, 1.5, -1.5, np.nan], np.float32)])
+    phi = np.zeros_like(u)
+    check(lib().rt_debug_math(7, ptr(u), None, u.shape[0], ptr(phi)))
+    ref = np.zeros_like(u)
+    L.orc_math_batch(7, ptr(u), u.shape[0], ptr(ref))
+    # outside [-1, 1] both sides return a NaN (sign and payload are the platform's: sqrt of a negative number)
+    assert np.array_equal(np.isnan(phi), np.isnan(ref)) and np.isnan(phi[-3:]).all() and not np.isnan(phi[:-3]).any()
+    bad = np.flatnonzero(phi[:-3].view(np.uint32) != ref[:-3].view(np.uint32))
+    assert bad.size == 0, "acos_s differs at %d inputs, first u=%r: gpu %r oracle %r" % (bad.size, u[bad[0]], phi[bad[0]], ref[bad[0]])
+    for arr in (theta, np.ascontiguousarray(phi[: 1 << 23])):
+        for op in (5, 6):
+            out = np.zeros_like(arr)
+            check(lib().rt_debug_math(op, ptr(arr), None, arr.shape[0], ptr(out)))
+            ref = np.zeros_like(arr)
+            L.orc_math_batch(op, ptr(arr), arr.shape[0], ptr(ref))
+            assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), "op %d differs" % op
     out = np.zeros_like(xp)
     check(lib().rt_debug_math(3, ptr(xp), ptr(yp), xp.shape[0], ptr(out)))
     ref = np.array([L.orc_math_pow(C.c_float(float(v)), C.c_float(float(yp[0]))) for v in xp], np.float32)
@@ -633,3 +653,23 @@ def test_scene_at_extreme_scale(gpu, scale_by):
     got, cnt = gpu_render(gsc, to_rt_params(op))
     assert cnt["rays_closest"] == ref["intersect_calls"] and cnt["rays_shadow"] == ref["occluded_calls"]
     assert np.array_equal(got, ref["rgba"]), "%d bytes differ" % int((got != ref["rgba"]).sum())
+
+
+def test_render_from_a_second_thread(scenes):
+    """Raytracer::render(false) renders on a thread of its own (raytracer.rs:527): hipSetDevice binds a thread, not the process,
+    so every entry point selects the scene's device again.  Same pixels from a fresh thread as from the calling one."""
+    import threading
+    osc, gsc = scenes("teapot")
+    op = oracle_params(width=80, height=60, spp=2, light_samples=2, bounces=3)
+    ref = osc.render(op)["rgba"]
+    box = {}
+
+    def work():
+        box["rgba"], box["cnt"] = gpu_render(gsc, to_rt_params(op))
+        box["ids"], _ = gpu_cast(gsc, to_rt_params(op))
+
+    t = threading.Thread(target=work)
+    t.start()
+    t.join()
+    assert np.array_equal(box["rgba"], ref)
+    assert np.array_equal(box["ids"], osc.cast_primary(op)[0])

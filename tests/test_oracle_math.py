@@ -1,6 +1,7 @@
 """The oracle's deterministic sin/cos/acos/pow against libm (numpy float64): they stand in for the
 platform libm behind f32::sin, f32::cos, f32::acos, f32::powf in the reference (geo.rs:106-143,
-common.rs:57), so the distance to a correctly rounded result is stated here: <= 0.5001 ulp."""
+common.rs:57), so the distance to the exact result is stated here: <= 0.5001 ulp for the double-precision
+definitions (ScreenParams, tone map), < 0.9 ulp for the samplers' single-precision ones."""
 import ctypes as C
 
 import numpy as np
@@ -40,6 +41,32 @@ def test_acos():
     assert L.orc_math_acos(C.c_float(1.0)) == 0.0
     assert L.orc_math_acos(C.c_float(-1.0)) == np.float32(np.pi)
     assert np.isnan(L.orc_math_acos(C.c_float(1.5)))
+
+
+def _batch(op, xs):
+    xs = np.ascontiguousarray(xs, np.float32)
+    out = np.zeros_like(xs)
+    ob.lib().orc_math_batch(op, xs.ctypes.data_as(C.c_void_p), xs.shape[0], out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def test_sampler_trig_on_every_reachable_input():
+    """f32::sin / cos / acos as random_sphere and random_hemisphere call them (geo.rs:101-145): the single-precision
+    definitions stay below 0.9 ulp of the exact value on every input the samplers can produce (xi = i * 2^-23, i < 2^23)
+    and on a dense sweep of the domains; tools/mathcheck.cpp is the exhaustive form (every float)."""
+    xi = np.arange(1 << 23, dtype=np.float32) * np.float32(2.0 ** -23)
+    theta = (np.float32(2.0) * np.float32(np.pi)) * xi
+    u = np.float32(1.0) - np.float32(2.0) * xi
+    phi = _batch(7, u)
+    assert _max_ulp(phi, np.arccos(u.astype(np.float64))) < 0.9
+    for x in (theta, phi, np.linspace(0, 6.2831855, 1_000_001).astype(np.float32)):
+        assert _max_ulp(_batch(5, x), np.sin(x.astype(np.float64))) < 0.9
+        assert _max_ulp(_batch(6, x), np.cos(x.astype(np.float64))) < 0.9
+    sweep = np.linspace(-1, 1, 1_000_001).astype(np.float32)
+    assert _max_ulp(_batch(7, sweep), np.arccos(sweep.astype(np.float64))) < 0.9
+    assert _batch(7, np.array([1.0, -1.0], np.float32)).tolist() == [0.0, float(np.float32(np.pi))]
+    assert _batch(5, np.zeros(1, np.float32))[0] == 0.0 and _batch(6, np.zeros(1, np.float32))[0] == 1.0
+    assert np.isnan(_batch(7, np.array([1.5, -1.5, np.nan], np.float32))).all()
 
 
 def test_pow_gamma():
