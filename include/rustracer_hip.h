@@ -128,6 +128,18 @@ int rt_render_device(rt_scene* scene, const rt_render_params* params, void* rgba
 int rt_cast_primary(rt_scene* scene, const rt_render_params* params, uint32_t* ids, float* t);
 int rt_cast_primary_device(rt_scene* scene, const rt_render_params* params, void* ids_dev, void* t_dev, void* stream);
 
+/* rt_cast_primary_device for callers that cannot allocate device memory: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  No counterpart in the reference.  Same arguments and the same ids / t as
+ * rt_cast_primary_device; the call itself makes no hipMalloc / hipFree (nor any allocating library call): the memory its
+ * kernel needs beyond ids_dev and t_dev (the work counters that rt_get_counters reads afterwards, and the traversal-stack
+ * overflow rows) lives in a static device array of the library, 16 MiB + 256 B per GPU, held until the process ends
+ * (rt_init looks up its device address).  Limits, rejected with RT_ERR_LIMIT / RT_ERR_INVALID and a clear text: the scene
+ * must already be resident on the GPU (uploading allocates: one earlier rt_cast_primary_device / rt_render_device call does
+ * it), and its BVH may need at most 32 traversal-stack entries per ray (16 in LDS + 16 rows of the static array; the
+ * 871,200-triangle stand-in needs 27).  The grid is capped at 1024 workgroups.  Every call on a GPU shares that GPU's
+ * array: calls that overlap in time on one GPU (two streams, two threads) race; calls on one stream do not. */
+int rt_cast_primary_noalloc(rt_scene* scene, const rt_render_params* params, void* ids_dev, void* t_dev, void* stream);
+
 /* Arbitrary rays (host arrays, 3 floats each): Scene::intersect and Scene::is_occluded. */
 int rt_intersect_rays(rt_scene* scene, const float* origins, const float* directions, uint32_t n, uint32_t* ids, float* t);
 int rt_occluded_rays(rt_scene* scene, const float* origins, const float* directions, const float* max_dist, uint32_t n, uint8_t* out);

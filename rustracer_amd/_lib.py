@@ -64,7 +64,7 @@ class Counters(C.Structure):
 # every symbol include/rustracer_hip.h declares
 EXPORTS = [
     "rt_last_error", "rt_init", "rt_scene_create", "rt_scene_destroy", "rt_scene_info_get", "rt_scene_lights", "rt_scene_bvh", "rt_scene_wide_bvh",
-    "rt_render", "rt_render_device", "rt_cast_primary", "rt_cast_primary_device", "rt_intersect_rays", "rt_occluded_rays",
+    "rt_render", "rt_render_device", "rt_cast_primary", "rt_cast_primary_device", "rt_cast_primary_noalloc", "rt_intersect_rays", "rt_occluded_rays",
     "rt_get_counters", "rt_set_option", "rt_tiles_per_shard", "rt_tiles_pack", "rt_tiles_unpack", "rt_screen_params",
     "rt_scene_new_named", "rt_scene_new_dragon_mesh", "rt_scene_export", "rt_make_dragon_standin", "rt_debug_math", "rt_debug_rng",
 ]
@@ -101,6 +101,7 @@ def lib():
     L.rt_render_device.argtypes = [vp, C.POINTER(RenderParams), vp, vp]
     L.rt_cast_primary.argtypes = [vp, C.POINTER(RenderParams), vp, vp]
     L.rt_cast_primary_device.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp]
+    L.rt_cast_primary_noalloc.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp]
     L.rt_intersect_rays.argtypes = [vp, vp, vp, u32, vp, vp]
     L.rt_occluded_rays.argtypes = [vp, vp, vp, vp, u32, vp]
     L.rt_get_counters.argtypes = [vp, C.POINTER(Counters)]

@@ -33,6 +33,33 @@ int fail(int code, const std::string& msg) {
 
 #define BIND(dev) HIP_TRY(hipSetDevice(dev))
 
+// Scratch of rt_cast_primary_noalloc (include/rustracer_hip.h): the two pieces of device memory the primary-cast kernel uses
+// beyond its inputs and outputs, which rt_cast_primary_device takes from hipMalloc'ed buffers of the scene (w_stats, d_ovf):
+//   bytes [0, 256)   the work counters of the call (ST_COUNT x u64), cleared at the start of every call;
+//   bytes [256, ...) the traversal-stack overflow rows, [row][global thread]: RT_NOALLOC_ROWS rows for a grid of at most
+//                    RT_NOALLOC_GRID workgroups (entries below RT_STACK_LDS live in LDS); written before they are read.
+// One copy per GPU, held until the process ends.  The array's name is only a host-side stand-in for the symbol: the device
+// address comes from hipGetSymbolAddress, once per device with that device current (scratch_for), and is what kernels get.
+#define RT_NOALLOC_ROWS 16u
+#define RT_NOALLOC_GRID 1024u
+#define RT_NOALLOC_BYTES (256u + RT_NOALLOC_ROWS * RT_NOALLOC_GRID * RT_BLOCK * 4u)   // 16 MiB + 256 B
+#define RT_MAX_DEVICES 64
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_BYTES];
+void* g_scratch_ptr[RT_MAX_DEVICES];   // device address of `scratch` on each GPU this process has asked for (nullptr: not yet)
+
+// Device address of this GPU's copy of `scratch`; `device` must be the current device.
+int scratch_for(int device, void** out) {
+    if (device < 0 || device >= RT_MAX_DEVICES) return fail(RT_ERR_LIMIT, "device index beyond the scratch table");
+    if (!g_scratch_ptr[device]) {
+        void* ptr = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) return fail(RT_ERR_HIP, "hipGetSymbolAddress(scratch) returned a null address");
+        g_scratch_ptr[device] = ptr;
+    }
+    *out = g_scratch_ptr[device];
+    return RT_OK;
+}
+
 template <class T>
 struct DevBuf {
     T* p = nullptr;
@@ -68,6 +95,8 @@ struct rt_scene {
     std::vector<uint32_t> lights;
     bool has_triangle_light = false;
     bool uploaded = false;
+    uint32_t ovf_rows = 0;                       // traversal-stack rows beyond RT_STACK_LDS that the trees of this scene can need
+    const unsigned long long* stats_src = nullptr;   // where the counters of the last call live (w_stats, or the no-alloc scratch)
 
     DevBuf<float4> d_nodes, d_tris, d_tri_nrm, d_sph, d_mats, d_wnodes, d_wprims;
     DevBuf<uint2> d_sph_aux;
@@ -199,6 +228,7 @@ int upload_scene(rt_scene* s) {
     const uint32_t stack_need = b.depth > 2 * s->wide.depth ? b.depth : 2 * s->wide.depth;
     const uint32_t ovf_rows = stack_need > RT_STACK_LDS ? stack_need - RT_STACK_LDS : 0;
     if (ovf_rows > 224) return fail(RT_ERR_LIMIT, "BVH deeper than 256 levels");
+    s->ovf_rows = ovf_rows;
 
     std::vector<float4> tris(3 * (size_t)T), nrm(3 * (size_t)T), sph(S ? S : 1), mats(2 * (size_t)(M ? M : 1));
     std::vector<uint2> aux(S ? S : 1);
@@ -344,6 +374,8 @@ struct Shard {
     uint32_t tiles_x, n_tiles, n_own_tiles;
     uint64_t n_own_pix;
 };
+// Owned pixels inside the image (edge tiles are clipped).
+uint64_t valid_pixels(const rt_render_params& P, const struct Shard& sh);
 Shard shard_of(const rt_render_params& P) {
     Shard s;
     s.tiles_x = (P.width + P.tile_w - 1) / P.tile_w;
@@ -352,6 +384,18 @@ Shard shard_of(const rt_render_params& P) {
     s.n_own_tiles = s.n_tiles > P.shard_index ? (s.n_tiles - P.shard_index + P.shard_count - 1) / P.shard_count : 0;
     s.n_own_pix = (uint64_t)s.n_own_tiles * P.tile_w * P.tile_h;
     return s;
+}
+
+uint64_t valid_pixels(const rt_render_params& P, const Shard& sh) {
+    uint64_t valid = 0;
+    for (uint32_t k = 0; k < sh.n_own_tiles; ++k) {
+        const uint32_t t = P.shard_index + k * P.shard_count;
+        const uint32_t x0 = (t % sh.tiles_x) * P.tile_w, y0 = (t / sh.tiles_x) * P.tile_h;
+        const uint32_t wv = x0 + P.tile_w <= P.width ? P.tile_w : (P.width > x0 ? P.width - x0 : 0);
+        const uint32_t hv = y0 + P.tile_h <= P.height ? P.tile_h : (P.height > y0 ? P.height - y0 : 0);
+        valid += (uint64_t)wv * hv;
+    }
+    return valid;
 }
 
 void begin_timing(rt_scene* s, hipStream_t stream, int cls, size_t* idx) {
@@ -374,6 +418,7 @@ void end_timing(rt_scene* s, hipStream_t stream, size_t idx) {
 
 void reset_counters(rt_scene* s, hipStream_t stream) {
     (void)hipMemsetAsync(s->w_stats.p, 0, ST_COUNT * sizeof(unsigned long long), stream);
+    s->stats_src = s->w_stats.p;
     s->events_used = 0;
     s->samples = 0;
     s->launches[0] = s->launches[1] = s->launches[2] = s->launches[3] = 0;
@@ -646,7 +691,8 @@ int rt_init(int device) {
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipFree(nullptr));
     g_device = device;
-    return RT_OK;
+    void* scratch_ptr = nullptr;
+    return scratch_for(device, &scratch_ptr);   // the no-alloc entry point's scratch: its device address is looked up here, once per GPU
 }
 
 int rt_scene_create(const float* tri_pos, const float* tri_nrm, const uint32_t* tri_mat, uint32_t n_tri, const float* sph,
@@ -743,6 +789,46 @@ int rt_cast_primary_device(rt_scene* s, const rt_render_params* params, void* id
     return cast_impl(s, params, (uint32_t*)ids_dev, (float*)t_dev, (hipStream_t)stream);
 }
 
+int rt_cast_primary_noalloc(rt_scene* s, const rt_render_params* params, void* ids_dev, void* t_dev, void* stream_) {
+    if (!s) return fail(RT_ERR_INVALID, "NULL scene");
+    if (!ids_dev && !t_dev) return fail(RT_ERR_INVALID, "NULL argument");
+    int rc;
+    if ((rc = validate_params(params))) return rc;
+    if (!s->uploaded)
+        return fail(RT_ERR_INVALID, "rt_cast_primary_noalloc: the scene is not resident on the GPU yet (uploading allocates): make one call of "
+                                    "rt_cast_primary_device or rt_render_device first");
+    if (s->ovf_rows > RT_NOALLOC_ROWS)
+        return fail(RT_ERR_LIMIT, "rt_cast_primary_noalloc: the scene's BVH is deeper than the static scratch holds (" + std::to_string(RT_STACK_LDS + RT_NOALLOC_ROWS) +
+                                  " stack entries per ray); use rt_cast_primary_device");
+    BIND(s->device);
+    void* ptr = nullptr;
+    if ((rc = scratch_for(s->device, &ptr))) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    const Shard sh = shard_of(*params);
+    s->events_used = 0;
+    s->launches[0] = 1; s->launches[1] = s->launches[2] = s->launches[3] = 0;
+    s->samples = 0;
+    s->stats_src = (const unsigned long long*)ptr;
+    // the counters start at zero; the overflow rows are written before they are read
+    HIP_TRY(hipMemsetAsync(ptr, 0, 256, stream));
+    if (sh.n_own_pix == 0) return RT_OK;
+    if (sh.n_own_pix >= (1ull << 31)) return fail(RT_ERR_LIMIT, "shard larger than 2^31 pixels");
+    uint32_t g = grid_for(s, sh.n_own_pix);
+    if (g > RT_NOALLOC_GRID) g = RT_NOALLOC_GRID;
+    DevScene d = s->dev;
+    d.ovf = (uint32_t*)((unsigned char*)ptr + 256);
+    d.ovf_stride = g * RT_BLOCK;
+    if (s->opt_stats)
+        hipLaunchKernelGGL(k_primary<true>, dim3(g), dim3(RT_BLOCK), 0, stream, d, *params, sh.tiles_x, (uint32_t)sh.n_own_pix, (uint32_t*)ids_dev,
+                           (float*)t_dev, (uint8_t*)nullptr, (unsigned long long*)ptr);
+    else
+        hipLaunchKernelGGL(k_primary<false>, dim3(g), dim3(RT_BLOCK), 0, stream, d, *params, sh.tiles_x, (uint32_t)sh.n_own_pix, (uint32_t*)ids_dev,
+                           (float*)t_dev, (uint8_t*)nullptr, (unsigned long long*)ptr);
+    HIP_TRY(hipGetLastError());
+    s->samples = valid_pixels(*params, sh);
+    return RT_OK;
+}
+
 int rt_cast_primary(rt_scene* s, const rt_render_params* params, uint32_t* ids, float* t) {
     if (!s || (!ids && !t)) return fail(RT_ERR_INVALID, "NULL argument");
     int rc;
@@ -801,7 +887,7 @@ int rt_get_counters(const rt_scene* cs, rt_counters* out) {
     BIND(s->device);
     HIP_TRY(hipDeviceSynchronize());
     unsigned long long st[ST_COUNT];
-    HIP_TRY(hipMemcpy(st, s->w_stats.p, sizeof st, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(st, s->stats_src ? s->stats_src : s->w_stats.p, sizeof st, hipMemcpyDeviceToHost));
     memset(out, 0, sizeof *out);
     out->rays_closest = st[ST_RAYS_CLOSEST];
     out->rays_shadow = st[ST_RAYS_SHADOW];
