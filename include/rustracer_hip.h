@@ -179,6 +179,10 @@ int rt_make_dragon_standin(uint32_t nu, uint32_t nv, float* vpos, float* vnrm, u
 /* op: 0 sin, 1 cos, 2 acos (double-precision definitions), 3 pow(x, y[i]), 4 to_color -> out as float,
  * 5 sin, 6 cos, 7 acos as the samplers evaluate them (single precision, rt_math.h sincos_s / acos_s) */
 int rt_debug_math(uint32_t op, const float* x, const float* y, uint32_t n, float* out);
+/* The kernels' short forms of IEEE f32 1/x (op 0), sqrt (1), a/b (2) and Ray::new's normalise + reciprocals (3) against the compiler's
+ * correctly rounded expansions, on the GPU: every float for 0 and 1, 2^35 / 2^32 operand sets for 2 and 3.  out2[0] = inputs whose results
+ * differ in any bit (must be 0), out2[1] = one such input. */
+int rt_debug_exact(uint32_t op, uint64_t* out2);
 int rt_debug_rng(uint64_t seed, uint32_t pixel_index, uint32_t sample, uint32_t n, float* out);
 
 #ifdef __cplusplus

@@ -66,7 +66,7 @@ EXPORTS = [
     "rt_last_error", "rt_init", "rt_scene_create", "rt_scene_destroy", "rt_scene_info_get", "rt_scene_lights", "rt_scene_bvh", "rt_scene_wide_bvh",
     "rt_render", "rt_render_device", "rt_cast_primary", "rt_cast_primary_device", "rt_cast_primary_noalloc", "rt_intersect_rays", "rt_occluded_rays",
     "rt_get_counters", "rt_set_option", "rt_tiles_per_shard", "rt_tiles_pack", "rt_tiles_unpack", "rt_screen_params",
-    "rt_scene_new_named", "rt_scene_new_dragon_mesh", "rt_scene_export", "rt_make_dragon_standin", "rt_debug_math", "rt_debug_rng",
+    "rt_scene_new_named", "rt_scene_new_dragon_mesh", "rt_scene_export", "rt_make_dragon_standin", "rt_debug_math", "rt_debug_rng", "rt_debug_exact",
 ]
 
 _lib = None
@@ -117,6 +117,7 @@ def lib():
     L.rt_scene_export.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.rt_make_dragon_standin.argtypes = [u32, u32, vp, vp, vp]
     L.rt_debug_math.argtypes = [u32, vp, vp, u32, vp]
+    L.rt_debug_exact.argtypes = [u32, vp]
     L.rt_debug_rng.argtypes = [u64, u32, u32, u32, vp]
     _lib = L
     return L

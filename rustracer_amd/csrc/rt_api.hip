@@ -1042,6 +1042,21 @@ int rt_debug_math(uint32_t op, const float* x, const float* y, uint32_t n, float
     return RT_OK;
 }
 
+int rt_debug_exact(uint32_t op, uint64_t* out2) {
+    if (!out2 || op > 3u) return fail(RT_ERR_INVALID, "bad argument");
+    BIND(g_device);
+    DevBuf<unsigned long long> dout;
+    struct Guard { DevBuf<unsigned long long>* a; ~Guard() { a->release(); } } guard{&dout};
+    int rc;
+    if ((rc = dout.ensure(2))) return rc;
+    HIP_TRY(hipMemset(dout.p, 0, 16));
+    hipLaunchKernelGGL(k_debug_exact, dim3(4096), dim3(256), 0, nullptr, op, dout.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out2, dout.p, 16, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
 int rt_debug_rng(uint64_t seed, uint32_t pixel_index, uint32_t sample, uint32_t n, float* out) {
     if (!out) return fail(RT_ERR_INVALID, "NULL argument");
     if (!n) return RT_OK;

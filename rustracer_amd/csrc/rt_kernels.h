@@ -140,6 +140,63 @@ __device__ __forceinline__ vec3 screen_to_world(const rt_render_params& P, uint3
     return unit3(mk(xi, yi, -P.z));
 }
 
+// ---- IEEE f32 reciprocal, division and square root without the compiler's range handling ------------------------------
+// hipcc expands `a / b` and `sqrtf(x)` (correctly rounded, the default) into 11 and 17 instructions: v_div_scale x2, v_rcp,
+// five fma, v_div_fmas, v_div_fixup; and v_sqrt, two +-1 ulp candidates with their fma residuals, plus rescaling for tiny
+// inputs.  Most of that only serves operands near the ends of the exponent range.  For operands in [2^-96, 2^96] the forms
+// below give the SAME bits with 5, 3 (per quotient, sharing the reciprocal) and 9 instructions; anything else (zero,
+// denormal, huge, inf, NaN) takes the compiler's expansion, so the result is the IEEE one for every input.
+//   rcp_mid:  y0 = v_rcp_f32(x) (1 ulp), two Newton steps with exact fma residuals.  Equal to 1.0f / x on every float of the
+//             range, checked exhaustively on the GPU (tests/test_gpu_parity.py::test_fast_ieee_forms_are_exact).
+//   div_mid:  q = a y, r = a - b q (exact, fma), q' = q + r y with y = RN(1 / b): the correctly rounded quotient (Markstein's
+//             theorem), for a and b in [2^-60, 2^60] so that q and r stay normal; checked on 2^35 operand pairs incl. every
+//             mantissa of b.
+//   sqrt_mid: the compiler's own algorithm minus the rescaling: s = v_sqrt_f32(x), then s - 1 ulp if x - (s - 1ulp) s <= 0,
+//             s + 1 ulp if x - (s + 1ulp) s > 0.  Checked exhaustively.
+__device__ __forceinline__ bool mid_range(float x) { const float a = fabsf(x); return a >= 0x1p-96f && a <= 0x1p+96f; }
+__device__ __forceinline__ bool div_range(float x) { const float a = fabsf(x); return a >= 0x1p-60f && a <= 0x1p+60f; }   // quotients and residuals stay normal
+__device__ __forceinline__ float rcp_mid(float x) {
+    float y = __builtin_amdgcn_rcpf(x);
+    float e = fmaf(-x, y, 1.0f);
+    y = fmaf(y, e, y);
+    e = fmaf(-x, y, 1.0f);
+    return fmaf(y, e, y);
+}
+__device__ __forceinline__ float div_mid(float a, float b, float rcp_b) {
+    const float q = a * rcp_b;
+    const float r = fmaf(-b, q, a);
+    return fmaf(r, rcp_b, q);
+}
+__device__ __forceinline__ float sqrt_mid(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rm = fmaf(-sm, s, x), rp = fmaf(-sp, s, x);
+    float out = rm <= 0.0f ? sm : s;
+    out = rp > 0.0f ? sp : out;
+    return out;
+}
+__device__ __forceinline__ float rcp_ieee(float x) {          // == 1.0f / x
+    if (mid_range(x)) return rcp_mid(x);
+    return 1.0f / x;
+}
+__device__ __forceinline__ float div_ieee(float a, float b) { // == a / b
+    if (div_range(a) && div_range(b)) return div_mid(a, b, rcp_mid(b));
+    return a / b;
+}
+__device__ __forceinline__ float sqrt_ieee(float x) {         // == sqrtf(x)
+    if (x >= 0x1p-96f && x <= 0x1p+96f) return sqrt_mid(x);
+    return sqrtf(x);
+}
+// unit3 (v / |v|, three divisions by one norm) and the three reciprocals of the result: Ray::new + bvh Ray::new (mod.rs:506-512)
+__device__ __forceinline__ vec3 unit3_ieee(vec3 a) {
+    const float n = sqrt_ieee(dot3(a, a));
+    if (div_range(n) && div_range(a.x) && div_range(a.y) && div_range(a.z)) {
+        const float y = rcp_mid(n);
+        return mk(div_mid(a.x, n, y), div_mid(a.y, n, y), div_mid(a.z, n, y));
+    }
+    return mk(a.x / n, a.y / n, a.z / n);
+}
+
 // bvh::ray::Ray::new as called from ray_to_bvh_ray (src/scene/mod.rs:506-512): the direction is
 // normalised again and the box tests use 1/d of that.
 struct BoxRay {
@@ -147,10 +204,14 @@ struct BoxRay {
     bool sx, sy, sz;
 };
 __device__ __forceinline__ BoxRay make_box_ray(vec3 o, vec3 d) {
-    const vec3 n = unit3(d);
+    const vec3 n = unit3_ieee(d);
     BoxRay r;
     r.ox = o.x; r.oy = o.y; r.oz = o.z;
-    r.ix = 1.0f / n.x; r.iy = 1.0f / n.y; r.iz = 1.0f / n.z;
+    if (mid_range(n.x) && mid_range(n.y) && mid_range(n.z)) {
+        r.ix = rcp_mid(n.x); r.iy = rcp_mid(n.y); r.iz = rcp_mid(n.z);
+    } else {
+        r.ix = 1.0f / n.x; r.iy = 1.0f / n.y; r.iz = 1.0f / n.z;
+    }
     r.sx = n.x < 0.0f; r.sy = n.y < 0.0f; r.sz = n.z < 0.0f;
     return r;
 }
@@ -183,7 +244,7 @@ __device__ __forceinline__ bool hit_triangle(vec3 p1, vec3 p2, vec3 p3, vec3 o, 
 // sends many rays from one origin).  Same operations on the same values, in the reference's order.
 __device__ __forceinline__ bool hit_triangle_o(vec3 e1, vec3 e2, vec3 s, vec3 s2, float tnum, vec3 d, float* t_out) {
     const vec3 s1 = cross3(d, e2);
-    const float scalar = 1.0f / dot3(s1, e1);
+    const float scalar = rcp_ieee(dot3(s1, e1));
     const float t = tnum * scalar;
     const float b1 = dot3(s1, s) * scalar;
     const float b2 = dot3(s2, d) * scalar;
@@ -985,9 +1046,9 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
           for (uint32_t ls = 0; ls < L; ++ls, ++j, sl += 64) {                 // for _ in 0..light_samples (raytracer.rs:269)
             const vec3 sp = add(xyz(cr), scale(random_sphere(&rng), cr.w));      // Sphere::random_point, objects.rs:223-226
             const vec3 ps = sub(sp, p);
-            const float d_s = length3(ps);
-            const vec3 wi = scale(ps, 1.0f / d_s);
-            const float cos_a = (d_c * d_c + cr.w * cr.w - d_s * d_s) / (2.0f * d_c * cr.w);
+            const float d_s = sqrt_ieee(dot3(ps, ps));
+            const vec3 wi = scale(ps, rcp_ieee(d_s));
+            const float cos_a = div_ieee(d_c * d_c + cr.w * cr.w - d_s * d_s, 2.0f * d_c * cr.w);
             const float pdf = 2.0f * RT_PI * (1.0f - cos_a);
             const float cos_theta = fabsf(dot3(wi, nrm));
             bool blocked = false;
@@ -1363,6 +1424,52 @@ __global__ void k_debug_math(uint32_t op, const float* x, const float* y, uint32
         default: r = (float)to_color(x[i]); break;
     }
     out[i] = r;
+}
+// Exhaustive equality of the fast IEEE forms with the compiler's: counts inputs whose results differ in any bit (two NaNs count as equal).
+// op 0: rcp_ieee(x) vs 1.0f / x, op 1: sqrt_ieee(x) vs sqrtf(x), every one of the 2^32 floats; op 2: div_ieee(a, b) vs a / b with b every mantissa at
+// five exponents and 1024 numerators each (hashed, of every exponent class); op 3: unit3_ieee / make_box_ray vs the plain forms on 2^32 hashed vectors.
+// out[0] = mismatches, out[1] = one offending input (bits; 64-bit for op 2).
+__device__ __forceinline__ bool same_bits(float a, float b) { return __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b); }
+__device__ __forceinline__ uint32_t hash32(uint64_t z) { return (uint32_t)(mix64(z) >> 16); }
+__global__ void k_debug_exact(uint32_t op, unsigned long long* out) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long bad = 0, which = 0;
+    if (op <= 1u) {
+        for (uint64_t b = tid; b < (1ull << 32); b += nthreads) {
+            const float x = __uint_as_float((uint32_t)b);
+            const bool ok = op == 0u ? same_bits(rcp_ieee(x), 1.0f / x) : same_bits(sqrt_ieee(x), sqrtf(x));
+            if (!ok) { ++bad; which = b; }
+        }
+    } else if (op == 2u) {
+        const uint32_t exps[5] = {127u - 60u, 127u - 1u, 127u, 127u + 37u, 127u + 59u};
+        for (uint64_t i = tid; i < 5ull * (1ull << 23); i += nthreads) {
+            const uint32_t bb = (exps[i >> 23] << 23) | (uint32_t)(i & 0x7FFFFFu) | ((i & 1u) ? 0x80000000u : 0u);
+            const float b = __uint_as_float(bb);
+            for (uint32_t k = 0; k < 1024u; ++k) {
+                uint32_t ab = hash32(i * 1024u + k);
+                if ((k & 7u) == 0u) ab = (ab & 0x807FFFFFu) | (bb & 0x7F800000u);          // same exponent as b: quotients near 1
+                if ((k & 63u) == 1u) ab = (k & 64u) ? 0x80000000u : 0u;                     // signed zeros
+                const float a = __uint_as_float(ab);
+                if (!same_bits(div_ieee(a, b), a / b)) { ++bad; which = ((unsigned long long)ab << 32) | bb; }
+            }
+        }
+    } else {
+        for (uint64_t i = tid; i < (1ull << 32); i += nthreads) {
+            // directions as the path tracer makes them: near-unit vectors, some with tiny, zero or huge components
+            const uint32_t h0 = hash32(3 * i), h1 = hash32(3 * i + 1), h2 = hash32(3 * i + 2);
+            vec3 d = mk(__uint_as_float((h0 & 0x807FFFFFu) | 0x3F000000u), __uint_as_float((h1 & 0x807FFFFFu) | 0x3E800000u), __uint_as_float((h2 & 0x807FFFFFu) | 0x3F000000u));
+            if ((i & 15u) == 0u) d.x = __uint_as_float(h0);                                  // any float at all
+            if ((i & 63u) == 1u) d.y = (i & 64u) ? -0.0f : 0.0f;
+            if ((i & 255u) == 2u) d.z = __uint_as_float(h2 & 0x80FFFFFFu);                   // denormal or tiny
+            const vec3 u0 = unit3(d), u1 = unit3_ieee(d);
+            const BoxRay br = make_box_ray(mk(0.0f, 0.0f, 0.0f), d);
+            const vec3 n = unit3(d);
+            const bool ok = same_bits(u0.x, u1.x) && same_bits(u0.y, u1.y) && same_bits(u0.z, u1.z) && same_bits(br.ix, 1.0f / n.x) &&
+                            same_bits(br.iy, 1.0f / n.y) && same_bits(br.iz, 1.0f / n.z);
+            if (!ok) { ++bad; which = i; }
+        }
+    }
+    if (bad) { atomicAdd(&out[0], bad); out[1] = which; }
 }
 __global__ void k_debug_rng(uint64_t seed_mixed, uint32_t pixel_index, uint32_t sample, uint32_t n, float* out) {
     if (blockIdx.x || threadIdx.x) return;

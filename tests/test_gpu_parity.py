@@ -673,3 +673,14 @@ def test_render_from_a_second_thread(scenes):
     t.join()
     assert np.array_equal(box["rgba"], ref)
     assert np.array_equal(box["ids"], osc.cast_primary(op)[0])
+
+
+@pytest.mark.parametrize("op,what", [(0, "1/x on every float"), (1, "sqrt on every float"), (2, "a/b on 2^35 pairs"), (3, "normalise + 1/d on 2^32 vectors")])
+def test_fast_ieee_forms_are_exact(gpu, op, what):
+    """The kernels replace hipcc's 11- and 17-instruction expansions of IEEE division and square root by shorter sequences for operands in
+    [2^-96, 2^96] (rt_kernels.h: rcp_mid, div_mid, sqrt_mid).  Those must give the compiler's (= the CPU's, = the reference's) bits on every
+    input: compared on the GPU itself, exhaustively where the domain allows."""
+    from rustracer_amd._lib import check, lib
+    out = np.zeros(2, np.uint64)
+    check(lib().rt_debug_exact(op, out.ctypes.data_as(C.c_void_p)))
+    assert out[0] == 0, "%s: %d inputs differ, e.g. 0x%x" % (what, int(out[0]), int(out[1]))
