@@ -149,7 +149,7 @@ int rt_get_counters(const rt_scene* scene, rt_counters* out);
  *   "stats" 0/1 traversal counters; "timing" 0/1 HIP-event kernel timing; "max_paths" camera samples in flight per pass;
  *   "wide" 0/1 is_occluded rays use the 8-wide occlusion BVH (default 1); "persist" 0/1 light samples go through the
  *   k_light + persistent k_trace_p pair (default 1); "hot" 0/1 per-light occluder cache (default 1; only before the first
- *   render); "self_test" 0/1 test the object a shadow ray starts on first (default 1); "root_in_light" 0/1 (default 0);
+ *   render); "self_test" 0/1 test the object a shadow ray starts on first (default 1);
  *   "refill_min" (16), "phase_bias" (4), "shadow_waves" (8), "light_waves" (4), "inner_min" (12): scheduling constants. */
 int rt_set_option(rt_scene* scene, const char* name, uint64_t value);
 

@@ -109,7 +109,6 @@ struct rt_scene {
     DevBuf<uint32_t> w_counts, w_hit_id, w_blist;
     DevBuf<float> w_hit_t;
     DevBuf<float4> w_ray_o[2], w_ray_d[2], w_vP, w_vN, w_vS, w_contrib, w_direct, w_stackA, w_stackB, w_radiance, w_accum;
-    DevBuf<float2> w_svis;
     DevBuf<float4> w_lray;
     DevBuf<uint64_t> w_rng;
     DevBuf<unsigned long long> w_tmask;
@@ -123,7 +122,7 @@ struct rt_scene {
 
     bool opt_stats = false, opt_timing = false;
     uint64_t opt_max_paths = 1ull << 24;
-    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 16, opt_phase_bias = 4, opt_shadow_waves = 8, opt_light_waves = 4, opt_hot = 1, opt_root_in_light = 0;
+    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 16, opt_phase_bias = 4, opt_shadow_waves = 8, opt_light_waves = 4, opt_hot = 1;
     uint32_t grid_max = 2048;
 
     std::vector<EventPair> events;
@@ -306,7 +305,7 @@ int upload_scene(rt_scene* s) {
     }
     d.ovf = s->d_ovf.p; d.ovf_stride = s->grid_max * RT_BLOCK;
     d.inner_min = s->opt_inner_min; d.self_test = s->opt_self_test;
-    d.wnodes = s->d_wnodes.p; d.wprims = s->d_wprims.p; d.wrec = s->d_wrec.p; d.root_in_light = s->opt_root_in_light;
+    d.wnodes = s->d_wnodes.p; d.wprims = s->d_wprims.p; d.wrec = s->d_wrec.p;
     {
         // Occluder cache of k_light: per light, the RT_HOT largest non-emissive objects whose box overlaps the light's box (a light
         // recessed into or poking through a wall has most of its samples blocked by that wall).  A choice of test order only.
@@ -511,7 +510,6 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
         if (!rc) rc = s->w_vN.ensure(cap_paths);
         if (!rc) rc = s->w_vS.ensure(cap_paths);
         if (!rc) rc = s->w_rng.ensure(cap_paths);
-        if (!rc && persist) rc = s->w_svis.ensure(cap_slots);
         if (!rc && persist) rc = s->w_lray.ensure(2 * cap_slots);
         if (!rc && persist) rc = s->w_blist.ensure(cap_slots);
         if (!rc && persist) rc = s->w_tmask.ensure(cap_slots / 64);
@@ -528,7 +526,7 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
         HIP_TRY(hipStreamSynchronize(stream));
         for (int q = 0; q < 2; ++q) { s->w_ray_o[q].release(); s->w_ray_d[q].release(); }
         s->w_hit_id.release(); s->w_hit_t.release(); s->w_vP.release(); s->w_vN.release(); s->w_vS.release(); s->w_rng.release();
-        s->w_svis.release(); s->w_lray.release(); s->w_blist.release(); s->w_tmask.release(); s->w_contrib.release(); s->w_direct.release();
+        s->w_lray.release(); s->w_blist.release(); s->w_tmask.release(); s->w_contrib.release(); s->w_direct.release();
         s->w_stackA.release(); s->w_stackB.release(); s->w_radiance.release(); s->w_accum.release();
     }
     if ((rc = ensure_jump(s, nlL, stream))) return rc;
@@ -543,7 +541,7 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
     for (int q = 0; q < 2; ++q) { pc.ray_o[q] = s->w_ray_o[q].p; pc.ray_d[q] = s->w_ray_d[q].p; }
     pc.hit_id = s->w_hit_id.p; pc.hit_t = s->w_hit_t.p;
     pc.vP = s->w_vP.p; pc.vN = s->w_vN.p; pc.rng = s->w_rng.p; pc.contrib = s->w_contrib.p; pc.direct = s->w_direct.p; pc.in_wave = in_wave ? 1u : 0u;
-    pc.svis = s->w_svis.p; pc.lray = s->w_lray.p; pc.blist = s->w_blist.p; pc.tmask = s->w_tmask.p; pc.persist = persist ? 1u : 0u;
+    pc.lray = s->w_lray.p; pc.blist = s->w_blist.p; pc.tmask = s->w_tmask.p; pc.persist = persist ? 1u : 0u;
     pc.stackA = s->w_stackA.p; pc.stackB = s->w_stackB.p; pc.radiance = s->w_radiance.p; pc.accum = s->w_accum.p;
     pc.jump = s->w_jump.p; pc.stats = s->w_stats.p; pc.rgba = rgba_dev;
 
@@ -586,14 +584,11 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
                     const uint32_t gs = grid_for(s, (uint64_t)pc.npaths * nlL);
                     begin_timing(s, stream, hemi ? 0 : (persist ? 3 : 1), &ev);
                     if (persist) {
-                        const bool root = s->opt_root_in_light != 0;
-                        if (s->opt_stats) { if (root) hipLaunchKernelGGL((k_light<true, 4, true>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level, s->hot_table);
-                                            else hipLaunchKernelGGL((k_light<true, 4, false>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level, s->hot_table); }
-                        else if (root) hipLaunchKernelGGL((k_light<false, 4, true>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level, s->hot_table);
-                        else if (s->opt_light_waves >= 8) hipLaunchKernelGGL((k_light<false, 8, false>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level, s->hot_table);
-                        else if (s->opt_light_waves >= 6) hipLaunchKernelGGL((k_light<false, 6, false>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level, s->hot_table);
-                        else if (s->opt_light_waves >= 5) hipLaunchKernelGGL((k_light<false, 5, false>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level, s->hot_table);
-                        else hipLaunchKernelGGL((k_light<false, 4, false>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level, s->hot_table);
+                        if (s->opt_stats) hipLaunchKernelGGL((k_light<true, 4>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level, s->hot_table);
+                        else if (s->opt_light_waves >= 8) hipLaunchKernelGGL((k_light<false, 8>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level, s->hot_table);
+                        else if (s->opt_light_waves >= 6) hipLaunchKernelGGL((k_light<false, 6>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level, s->hot_table);
+                        else if (s->opt_light_waves >= 5) hipLaunchKernelGGL((k_light<false, 5>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level, s->hot_table);
+                        else hipLaunchKernelGGL((k_light<false, 4>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level, s->hot_table);
                         end_timing(s, stream, ev);
                         begin_timing(s, stream, 2, &ev);
                         if (s->opt_stats) hipLaunchKernelGGL(k_binary<true>, dim3(64), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
@@ -730,7 +725,7 @@ void rt_scene_destroy(rt_scene* s) {
     s->w_counts.release(); s->w_hit_id.release(); s->w_blist.release(); s->w_hit_t.release();
     for (int q = 0; q < 2; ++q) { s->w_ray_o[q].release(); s->w_ray_d[q].release(); }
     s->w_vP.release(); s->w_vN.release(); s->w_vS.release(); s->w_contrib.release(); s->w_direct.release(); s->w_stackA.release(); s->w_stackB.release();
-    s->w_radiance.release(); s->w_accum.release(); s->w_svis.release(); s->w_tmask.release(); s->w_lray.release(); s->w_rng.release(); s->w_jump.release(); s->w_stats.release();
+    s->w_radiance.release(); s->w_accum.release(); s->w_tmask.release(); s->w_lray.release(); s->w_rng.release(); s->w_jump.release(); s->w_stats.release();
     s->w_frame.release(); s->w_ids.release(); s->w_ts.release(); s->w_rays.release();
     for (size_t i = 0; i < s->events.size(); ++i) { (void)hipEventDestroy(s->events[i].a); (void)hipEventDestroy(s->events[i].b); }
     delete s;
@@ -916,7 +911,6 @@ int rt_set_option(rt_scene* s, const char* name, uint64_t value) {
     else if (n == "self_test") { s->opt_self_test = value ? 1 : 0; s->dev.self_test = s->opt_self_test; }
     else if (n == "wide") { s->opt_wide = value ? 1 : 0; s->dev.n_wnodes = (s->wide.ok && s->opt_wide) ? s->wide.n_nodes() : 0u; }
     else if (n == "persist") s->opt_persist = value ? 1 : 0;
-    else if (n == "root_in_light") { s->opt_root_in_light = value ? 1 : 0; s->dev.root_in_light = s->opt_root_in_light; }
     else if (n == "hot") { if (s->uploaded) return fail(RT_ERR_INVALID, "option 'hot' must be set before the first render"); s->opt_hot = value ? 1 : 0; }
     else if (n == "shadow_waves") s->opt_shadow_waves = (uint32_t)value;
     else if (n == "light_waves") s->opt_light_waves = (uint32_t)value;

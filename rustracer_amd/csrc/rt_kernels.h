@@ -53,7 +53,6 @@ struct DevScene {
     const float4* wnodes;    // occlusion BVH (host_scene.h WideBVH): 5 x float4 per 8-wide node (80 B)
     const float4* wprims;    // 3 x float4 per blocker primitive record (48 B), in node order
     const uint32_t* wrec;    // primitive record of each object in wprims (0xFFFFFFFF: emissive, not in the tree)
-    uint32_t root_in_light;  // k_light tests the root node of the occlusion BVH (else k_trace_p starts there)
     uint32_t n_wnodes;       // 0: shadow rays take the binary tree
     uint32_t refill_min;     // k_trace_p: idle lanes that trigger a refill of the wave
     uint32_t phase_bias;     // k_trace_p: node step when 4 * lanes_at_nodes >= phase_bias * lanes_at_primitives
@@ -100,10 +99,10 @@ struct PassCtx {
     float4* contrib;                 // per (vertex, light sample): (rgb, visible); only when !in_wave
     float4* direct;                  // per vertex: light-sample sum (in_wave)
     uint32_t in_wave;                // nlL divides 64: k_shadow sums a vertex's light samples inside the wave
-    float2* svis;                    // per light-sample slot (ls_slot), k_light: (|wi.n|, sign bit set = dead / occluded, pdf)
-    unsigned long long* tmask;       // per row of 64 light-sample slots, k_light: the slots k_trace_p has to trace
-    float4* lray;                    // per light-sample slot, k_light: rays still to trace, 2 x float4: (wi, distance to the light sample), (1/d of the box test, 0)
-    uint32_t persist;                // light samples go through k_light + k_trace_p; k_shade_b sums pc.svis
+    unsigned long long* tmask;       // per row (64 vertices x one light sample), k_light: the vertices whose ray is not yet settled as blocked
+    float4* lray;                    // those rays, packed at the front of their row in lane order, 2 x float4 each: (wi, distance to the light sample),
+                                     // (1/d of the box test, word: RT_LR_* | occlusion-BVH record of the object the ray starts on)
+    uint32_t persist;                // light samples go through k_light + k_trace_p; k_shade_b sums the rays left unblocked in pc.lray
     float4* stackA;                  // [level][slot] (direct rgb, cos)
     float4* stackB;                  // [level][slot] (reflected rgb, pdf)
     float4* radiance;                // per path slot: finished sample
@@ -980,12 +979,18 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SHADOW_WAVES) k_shadow(DevScene s
 //              occlusion BVH that refills finished lanes (per-ray cost varies 1..40 nodes).
 // Slot of (vertex e, light sample j): tiles of 64 vertices, sample-major inside a tile, so that
 // k_light (lane = vertex), k_trace_p (row of 64 slots) and k_shade_b (lane = vertex) all touch
-// consecutive addresses.  pc.svis[slot] = (|wi.n|, pdf), sign bit of x set when the sample does not
-// count (dead vertex or occluded); pc.lray[slot] = (wi, distance) for rays that k_trace_p must trace.
+// consecutive addresses.  Most rays are settled as blocked in k_light (the object the ray starts on, the
+// occluder cache) and leave no record at all: they add nothing to the sum of raytracer.rs:279.  The others
+// are packed at the front of their row (pc.tmask[row] says which vertices they belong to; a ray's place is
+// the number of set bits below its lane), so that the kernels after k_light touch whole 64-byte sectors.
+// What the reference computes for a visible sample only (pdf, |wi.n|) is left to k_shade_b.
+#define RT_LR_BLOCKED 0x80000000u   // set by k_trace_p / k_binary: the ray is occluded
+#define RT_LR_LANE_SHIFT 23         // bits 23..28: the ray's vertex within its tile of 64 (bits 0..22: the record of the object it starts on)
+#define RT_LR_BINARY 0x40000000u    // the ray has a non-finite or huge 1/d: k_binary settles it on the binary tree, k_trace_p drops it
 __device__ __forceinline__ size_t ls_slot(uint32_t e, uint32_t j, uint32_t nlL) {
     return (size_t)(e >> 6) * (64u * (size_t)nlL) + (size_t)j * 64u + (e & 63u);
 }
-template <bool STATS, int WAVES, bool ROOT>   // WAVES: waves per SIMD the register budget is sized for; ROOT: test the BVH root here
+template <bool STATS, int WAVES>   // WAVES: waves per SIMD the register budget is sized for
 __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx pc, uint32_t level, HotTable hot) {
     TravStats tst = {0, 0, 0, 0, 0};
     const uint32_t n = pc.vcounts[level], n_round = (n + 63u) & ~63u;
@@ -997,7 +1002,7 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
         const uint32_t e = live ? e0 : 0u;
         const float4 N4 = pc.vN[e];
         const float4 P4 = pc.vP[e];
-        const vec3 p = xyz(P4), nrm = xyz(N4);
+        const vec3 p = xyz(P4);
         const uint64_t rng0 = pc.rng[__float_as_uint(pc.vS[e].x)];
         // the object the rays start on, fetched once per vertex (see self_blocks())
         const uint32_t self_obj = sc.self_test ? __float_as_uint(N4.w) - 1u : RT_MISS;
@@ -1022,12 +1027,11 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
         const vec3 own_s2 = cross3(own_s, own_e1);
         const float own_tn = dot3(own_s2, own_e2);
         uint64_t rng = rng0;                                                   // the vertex's stream: two draws per light sample, in sample order
-        size_t sl = ls_slot(e0, 0, nlL);                                       // slot of sample j: + 64 per sample
-        unsigned long long* row_mask = pc.tmask + (size_t)(e0 >> 6) * nlL;    // row of (this tile, sample j): + 1 per sample
+        size_t row = ls_slot(e0 & ~63u, 0, nlL);                               // first slot of the row of (this tile, sample j): + 64 per sample
+        unsigned long long* row_mask = pc.tmask + (size_t)(e0 >> 6) * nlL;    // mask of that row: + 1 per sample
         for (uint32_t g = 0, j = 0; g < pc.n_groups; ++g) {                    // for light in lights (raytracer.rs:266): per-light values stay in registers
           const uint32_t light = sc.lights[g];
           const float4 cr = sc.sph[light - sc.n_tri];
-          const float d_c = length3(sub(xyz(cr), p));
           // Occluder cache: is_occluded is "some non-emissive object blocks", whichever is found first, so the large occluders next
           // to this light (chosen at scene build: a ceiling the lamp pokes through blocks 4 of 5 samples of the Cornell lamp) are
           // tested here, by every lane and from registers, before any ray is queued for traversal.  Same exact tests as at a leaf.
@@ -1043,14 +1047,11 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
               hot_s2[h] = cross3(hot_s[h], mk(hr.e1[0], hr.e1[1], hr.e1[2]));
               hot_tn[h] = dot3(hot_s2[h], mk(hr.e2[0], hr.e2[1], hr.e2[2]));
           }
-          for (uint32_t ls = 0; ls < L; ++ls, ++j, sl += 64) {                 // for _ in 0..light_samples (raytracer.rs:269)
+          for (uint32_t ls = 0; ls < L; ++ls, ++j, row += 64) {                // for _ in 0..light_samples (raytracer.rs:269)
             const vec3 sp = add(xyz(cr), scale(random_sphere(&rng), cr.w));      // Sphere::random_point, objects.rs:223-226
             const vec3 ps = sub(sp, p);
             const float d_s = sqrt_ieee(dot3(ps, ps));
-            const vec3 wi = scale(ps, rcp_ieee(d_s));
-            const float cos_a = div_ieee(d_c * d_c + cr.w * cr.w - d_s * d_s, 2.0f * d_c * cr.w);
-            const float pdf = 2.0f * RT_PI * (1.0f - cos_a);
-            const float cos_theta = fabsf(dot3(wi, nrm));
+            const vec3 wi = scale(ps, rcp_ieee(d_s));                            // objects.rs:106-108; pdf and |wi.n| (objects.rs:109-115, raytracer.rs:278): k_shade_b, for the visible
             bool blocked = false;
             const BoxRay br = make_box_ray(p, wi);
             const bool binary = !wide_ray_ok(br, p);
@@ -1084,27 +1085,16 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
                     blocked = ok;
                 }
             }
-            // 0 * inf = NaN cases of the slab test, or far-away coordinates: k_binary settles these few on the binary tree, which
-            // has the crate's NaN behaviour
-            uint32_t root_hits = 0u;
-            if (!ROOT && !blocked && !binary) root_hits = 0x100u;    // k_trace_p starts at the root
-            if (ROOT && !blocked && !binary) {
-                // the root of the occlusion BVH (every traced ray's first node): tested here, with every lane busy
-                const float4* rp = sc.wnodes;
-                asm volatile("" : "+s"(rp));
-                if (STATS) tst.wide++;
-                root_hits = wide_child_mask(br, prune_limit(d_s), rp[0], rp[2], rp[3], rp[4]);
+            // a ray not settled here leaves a record: k_trace_p searches the occlusion BVH for a blocker; the few with a 0 * inf = NaN
+            // case in their slab test, or far-away coordinates, go to k_binary and the binary tree, which has the crate's NaN behaviour
+            const bool keep = live && !blocked;
+            const unsigned long long m = __ballot(keep);      // the whole wave is here: one row of 64 slots
+            if (keep) {
+                const size_t at = row + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                pc.lray[2 * at] = make_float4(wi.x, wi.y, wi.z, d_s);
+                pc.lray[2 * at + 1] = make_float4(br.ix, br.iy, br.iz, __uint_as_float(self_rec | (__lane_id() << RT_LR_LANE_SHIFT) | (binary ? RT_LR_BINARY : 0u)));
+                if (binary) pc.blist[atomicAdd(&pc.bcounts[level], 1u)] = (uint32_t)at;
             }
-            const bool trace = live && root_hits != 0u;      // no root slot hit: nothing can block the ray
-            if (live) {
-                pc.svis[sl] = make_float2(__uint_as_float(__float_as_uint(cos_theta) | (blocked ? 0x80000000u : 0u)), pdf);
-                if (binary) pc.blist[atomicAdd(&pc.bcounts[level], 1u)] = (uint32_t)sl;
-                if (trace || binary) {
-                    pc.lray[2 * sl] = make_float4(wi.x, wi.y, wi.z, d_s);
-                    pc.lray[2 * sl + 1] = make_float4(br.ix, br.iy, br.iz, __uint_as_float(self_rec | (root_hits << 23)));
-                }
-            }
-            const unsigned long long m = __ballot(trace);     // the whole wave is here: one row of 64 slots
             if (__lane_id() == 0u) row_mask[j] = m;
           }
         }
@@ -1117,24 +1107,25 @@ template <bool STATS>
 __global__ void __launch_bounds__(RT_BLOCK) k_binary(DevScene sc, PassCtx pc, uint32_t level) {
     RT_STACK_DECL;
     TravStats tst = {0, 0, 0, 0, 0};
-    const uint32_t n = pc.bcounts[level], nlL = pc.nlL;
-    uint32_t* flags = reinterpret_cast<uint32_t*>(pc.svis);
+    const uint32_t n = pc.bcounts[level];
+    uint32_t* words = reinterpret_cast<uint32_t*>(pc.lray);
     for (uint32_t i0 = blockIdx.x * RT_BLOCK + (threadIdx.x & ~63u); i0 < n; i0 += gridDim.x * RT_BLOCK) {
         const uint32_t i = i0 + (threadIdx.x & 63u);
         const bool have = i < n;
         vec3 o = mk(0.0f, 0.0f, 0.0f), d = mk(0.0f, 0.0f, 1.0f);
         float max_dist = 0.0f;
-        uint32_t self_obj = RT_MISS, sl = 0u;
+        uint32_t self_obj = RT_MISS;
+        size_t at = 0;
         if (have) {
-            sl = pc.blist[i];
-            const uint32_t e = sl / (64u * nlL) * 64u + (sl & 63u);
-            const float4 R4 = pc.lray[2 * (size_t)sl];
+            at = pc.blist[i];
+            const float4 R4 = pc.lray[2 * at];
+            const uint32_t e = (uint32_t)(at / (64u * (size_t)pc.nlL)) * 64u + ((words[8 * at + 7] >> RT_LR_LANE_SHIFT) & 63u);
             o = xyz(pc.vP[e]); d = xyz(R4); max_dist = R4.w;
             if (sc.self_test) self_obj = __float_as_uint(pc.vN[e].w) - 1u;
         }
         bool occ = false;
         traverse<1, STATS>(sc, have, o, d, max_dist, self_obj, st, nullptr, nullptr, &occ, &tst);
-        if (have && occ) flags[2 * (size_t)sl] |= 0x80000000u;
+        if (have && occ) words[8 * at + 7] |= RT_LR_BLOCKED;
     }
     flush_stats<STATS>(pc.stats, tst, ST_S_INNER);
 }
@@ -1159,15 +1150,15 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
     uint32_t row_base = 0u, row_tile = 0u;                                     // current row: first slot, vertex tile (vertex = row_tile * 64 + lane)
     uint32_t tile = next / (64u * nlL), jrow = (next >> 6) % nlL;              // tile and light sample of the row at `next`
     const uint32_t refill_min = sc.refill_min, phase_bias = sc.phase_bias;
-    uint32_t* flags = reinterpret_cast<uint32_t*>(pc.svis);
+    uint32_t* words = reinterpret_cast<uint32_t*>(pc.lray);
+    unsigned long long row_full = 0ull;                                        // all rays of the current row: a ray's record is at row_base + (set bits below its lane)
     // rays to trace of the row at `next` (k_light's vote), loaded one refill ahead
     unsigned long long m_next = next < n_slots ? pc.tmask[next >> 6] : 0ull;
 
     uint32_t w_steps[6] = {0, 0, 0, 0, 0, 0};   // STATS: wave steps and the lanes that took part (node, primitive, refill)
 
     // the ray this lane is tracing (cur != 0)
-    const uint32_t root_meta = __float_as_uint(sc.wnodes[0].w), root_child = __float_as_uint(sc.wnodes[1].x), root_prim = __float_as_uint(sc.wnodes[1].y);
-    uint32_t cur = 0u, slot = 0u, cos_bits = 0u, skip_rec = RT_W_NO_REC;
+    uint32_t cur = 0u, slot = 0u, rec_word = 0u, skip_rec = RT_W_NO_REC;
     vec3 o = mk(0.0f, 0.0f, 0.0f), d = mk(0.0f, 0.0f, 1.0f);
     BoxRay br = make_box_ray(o, d);
     float max_dist = 0.0f, lim = 0.0f;
@@ -1178,6 +1169,7 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
         if ((pend != 0ull || next < n_slots) && n_idle >= refill_min) {
             if (pend == 0ull) {                                  // next row of 64 slots: which rays are still to trace
                 pend = m_next;
+                row_full = m_next;
                 row_base = next;
                 row_tile = tile;
                 next += 64u;
@@ -1196,7 +1188,8 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
             const uint32_t take = n_pend < n_idle ? n_pend : n_idle;
             const bool offered = ((pend >> lane) & 1ull) != 0ull;
             const uint32_t prank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pend >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pend, 0u));
-            if (offered && prank < take) pub[prank] = lane;
+            if (offered && prank < take)     // (lane, place of its record in the row)
+                pub[prank] = lane | (__builtin_amdgcn_mbcnt_hi((uint32_t)(row_full >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)row_full, 0u)) << 8);
             pend = __ballot(offered && prank >= take);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -1204,27 +1197,20 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
             const bool mine = cur == 0u && irank < take;
             if (STATS) { w_steps[4]++; w_steps[5] += take; }
             if (mine) {
-                const uint32_t src = pub[irank];
-                slot = row_base + src;
+                const uint32_t got = pub[irank], src = got & 63u;
+                slot = row_base + (got >> 8);
                 const uint32_t e = row_tile * 64u + src;
                 const float4 R4 = pc.lray[2 * (size_t)slot], I4 = pc.lray[2 * (size_t)slot + 1];
                 const float4 P4 = pc.vP[e];
-                cos_bits = flags[2 * (size_t)slot];
+                rec_word = __float_as_uint(I4.w);
                 o = xyz(P4); d = xyz(R4); max_dist = R4.w;
                 br.ox = o.x; br.oy = o.y; br.oz = o.z;
                 br.ix = I4.x; br.iy = I4.y; br.iz = I4.z;                     // make_box_ray(o, d), computed by k_light
-                skip_rec = __float_as_uint(I4.w) & RT_W_NO_REC;                // the object the ray starts on: tested by k_light
+                skip_rec = rec_word & RT_W_NO_REC;                             // the object the ray starts on: tested by k_light
                 br.sx = I4.x < 0.0f; br.sy = I4.y < 0.0f; br.sz = I4.z < 0.0f; // sign of the normalised direction (finite 1/d only: wide_ray_ok)
                 lim = prune_limit(max_dist);
                 st.sp = 0;
-                if (sc.root_in_light) {               // k_light has tested the root node: the ray starts at the root's hit slots
-                    uint32_t a, b;
-                    wide_groups(__float_as_uint(I4.w) >> 23, root_meta, root_child, root_prim, skip_rec, &a, &b);
-                    if (a && b) st.push(b);
-                    cur = a ? a : b;
-                } else {
-                    cur = 1u;                         // inner group {node 0}
-                }
+                cur = (rec_word & RT_LR_BINARY) ? 0u : 1u;                     // inner group {node 0}; k_binary's rays are not traced here
             }
             __builtin_amdgcn_wave_barrier();
             continue;
@@ -1238,7 +1224,7 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
             if (at_node) wide_node_step<STATS>(sc, br, lim, skip_rec, cur, st, &tst);
         } else {
             if (STATS) { w_steps[2]++; w_steps[3] += n_prim; }
-            if (at_prim && wide_prim_step<STATS>(sc, br, o, d, max_dist, cur, st, &tst)) flags[2 * (size_t)slot] = cos_bits | 0x80000000u;
+            if (at_prim && wide_prim_step<STATS>(sc, br, o, d, max_dist, cur, st, &tst)) words[8 * (size_t)slot + 7] = rec_word | RT_LR_BLOCKED;
         }
     }
     flush_stats<STATS>(pc.stats, tst, ST_S_INNER);
@@ -1276,21 +1262,45 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_b(DevScene sc, PassCtx pc, u
                 const vec3 p = xyz(P4), nrm = xyz(N4);
                 vec3 l = mk(0.0f, 0.0f, 0.0f);
                 if (pc.persist) {
-                    // one_bounce_radiance_importance's sample loop (raytracer.rs:266-283) over what k_light / k_trace_p left per ray
+                    // one_bounce_radiance_importance's sample loop (raytracer.rs:266-283) over the rays k_light / k_trace_p / k_binary left unblocked;
+                    // a blocked sample adds nothing.  pdf (objects.rs:109-115) and |wi.n| (raytracer.rs:278) are worked out here, for those only.
                     const vec3 f = __float_as_uint(m0.x) == RT_BSDF_DIFFUSE ? scale(mk(m0.y, m0.z, m0.w), 1.0f / RT_PI) : mk(0.0f, 0.0f, 0.0f);   // Object::bsdf
+                    const uint32_t lane = __lane_id();
+                    const uint32_t* words = reinterpret_cast<const uint32_t*>(pc.lray);
                     for (uint32_t g = 0; g < pc.n_groups; ++g) {
                         const uint32_t light = sc.lights[g];
+                        const float4 cr = sc.sph[light - sc.n_tri];
                         const vec3 le = xyz(sc.mats[2 * (sc.sph_aux[light - sc.n_tri].y & ~RT_INFO_BLOCKER) + 1]);
                         const vec3 base = mul3(le, f);
+                        const float d_c = length3(sub(xyz(cr), p));
                         vec3 color = mk(0.0f, 0.0f, 0.0f);
-                        const float2* vp = pc.svis + ls_slot(e, g * L, pc.nlL);       // sample s of this vertex: vp[64 * s]
-                        for (uint32_t s0 = 0; s0 < L; s0 += 8) {                         // 8 loads in flight, then added in sample order
-                            float2 v[8];
+                        const size_t row0 = ls_slot(e & ~63u, g * L, pc.nlL);                                  // first slot of the row of sample s: + 64 s
+                        const unsigned long long* mrow = pc.tmask + (size_t)(e >> 6) * pc.nlL + (size_t)g * L;  // mask of that row: + s
+                        for (uint32_t s0 = 0; s0 < L; s0 += 8) {                         // 8 samples in flight, then added in sample order
+                            unsigned long long mk8[8];
+                            uint32_t w[8];
+                            float4 r[8];
 #pragma unroll
-                            for (uint32_t k = 0; k < 8; ++k) v[k] = vp[64 * (size_t)(s0 + k < L ? s0 + k : L - 1)];
+                            for (uint32_t k = 0; k < 8; ++k) mk8[k] = s0 + k < L ? mrow[s0 + k] : 0ull;
+#pragma unroll
+                            for (uint32_t k = 0; k < 8; ++k) {
+                                w[k] = RT_LR_BLOCKED;
+                                r[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                                if ((mk8[k] >> lane) & 1ull) {
+                                    const size_t at = row0 + 64 * (size_t)(s0 + k) + (size_t)__popcll(mk8[k] & ((1ull << lane) - 1ull));
+                                    w[k] = words[8 * at + 7];
+                                    r[k] = pc.lray[2 * at];
+                                }
+                            }
 #pragma unroll
                             for (uint32_t k = 0; k < 8; ++k)
-                                if (s0 + k < L && !(__float_as_uint(v[k].x) & 0x80000000u)) color = add(color, scale(scale(base, v[k].x), v[k].y));   // raytracer.rs:279
+                                if (!(w[k] & RT_LR_BLOCKED)) {
+                                    const float d_s = r[k].w;
+                                    const float cos_a = div_ieee(d_c * d_c + cr.w * cr.w - d_s * d_s, 2.0f * d_c * cr.w);   // Object::sample_l, objects.rs:109-113
+                                    const float pdf = 2.0f * RT_PI * (1.0f - cos_a);
+                                    const float cos_theta = fabsf(dot3(xyz(r[k]), nrm));                                  // raytracer.rs:278
+                                    color = add(color, scale(scale(base, cos_theta), pdf));                               // raytracer.rs:279
+                                }
                         }
                         l = add(l, scale(color, inv_light_samples));                // raytracer.rs:282
                     }

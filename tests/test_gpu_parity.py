@@ -268,14 +268,14 @@ def test_occluder_cache_and_scheduling_switches_do_not_change_a_pixel(gpu):
     osc, gsc = _two_light_scene()
     ref = osc.render(op)
     p = to_rt_params(op)
-    for opts in ({}, {"root_in_light": 1}, {"self_test": 0}, {"refill_min": 1, "phase_bias": 1}, {"refill_min": 64, "phase_bias": 16, "shadow_waves": 5},
-                 {"light_waves": 8, "root_in_light": 0}):
+    for opts in ({}, {"self_test": 0}, {"refill_min": 1, "phase_bias": 1}, {"refill_min": 64, "phase_bias": 16, "shadow_waves": 5},
+                 {"light_waves": 8}):
         for k, v in opts.items():
             gsc.set_option(k, v)
         got, cnt = gpu_render(gsc, p)
         assert np.array_equal(got, ref["rgba"]), opts
         assert cnt["rays_shadow"] == ref["occluded_calls"], opts
-        for k, v in {"root_in_light": 0, "self_test": 1, "refill_min": 16, "phase_bias": 4, "shadow_waves": 8, "light_waves": 4}.items():
+        for k, v in {"self_test": 1, "refill_min": 16, "phase_bias": 4, "shadow_waves": 8, "light_waves": 4}.items():
             gsc.set_option(k, v)
     with pytest.raises(Exception):
         gsc.set_option("hot", 0)                           # the cache is chosen at the first render
