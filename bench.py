@@ -67,18 +67,35 @@ def main():
     from rustracer_amd._lib import RT_MODE_FULL, check, lib
     from rustracer_amd.raytracer import Config, RenderConfig, make_params
 
-    # RT_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share devices; not a measurement)
-    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    # Data path: the library's own RCCL communicator (rt_comm_*: pack -> ncclAllGather -> unpack on the render stream).  torch.distributed is
+    # only the control plane (gloo on the host: the unique id, the barrier, the reduction of the timings).
+    # RT_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share devices, where RCCL refuses to
+    # start; the tiles then travel through the host; not a measurement).
+    backend = os.environ.get("RT_BENCH_BACKEND", "rccl")
+    dev_index = local_rank if backend == "rccl" else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
     check(lib().rt_init(dev_index))
     dev = torch.device("cuda", dev_index)
+    comm, gather_note = None, None
     if world > 1:
         import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        dist.init_process_group("gloo")
+        if backend == "rccl":
+            def bcast(ident):
+                box = [ident]
+                dist.broadcast_object_list(box, src=0)
+                return box[0]
+            try:
+                comm = tiles.Comm(world, rank, bcast)
+            except Exception as e:   # keep the run alive and say so in the line: a scaling number through the host is still a number
+                gather_note = "native RCCL communicator failed (%s): tiles gathered through the host with gloo" % (e,)
+            flags = [None] * world
+            dist.all_gather_object(flags, gather_note)
+            if any(flags):
+                gather_note = next(f for f in flags if f)
+                if comm is not None:
+                    comm.destroy()
+                comm = None
 
     # ---- scene (replicated on every rank; the BVH is built on the host) ----
     dragon_obj = os.path.join(ROOT, "obj", "dragon.obj")
@@ -107,7 +124,9 @@ def main():
 
     def step():
         check(lib().rt_render_device(scene.handle, C.byref(params), frame.data_ptr(), stream))
-        if world > 1:
+        if comm is not None:
+            comm.gather(params, frame.data_ptr(), stream)      # in place: every rank ends up with the whole frame
+        elif world > 1:
             return tiles.gather_frame(frame, a.width, a.height, tile[0], tile[1], rank, world)
         return frame
 
@@ -129,8 +148,8 @@ def main():
     scene.set_option("timing", 0)
 
     cnt = scene.counters()   # counts and HIP-event kernel times of the last timed step of this rank
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    tot = torch.tensor([cnt["rays_closest"], cnt["rays_shadow"], cnt["samples"]], dtype=torch.float64, device=dev)
+    el = torch.tensor([elapsed], dtype=torch.float64)
+    tot = torch.tensor([cnt["rays_closest"], cnt["rays_shadow"], cnt["samples"]], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -139,6 +158,8 @@ def main():
     rays_per_step = rays_closest + rays_shadow
     ms_per_step = elapsed / a.steps * 1e3
 
+    if comm is not None:
+        comm.destroy()
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -149,6 +170,7 @@ def main():
     # light samples), k_trace_p (Scene::is_occluded for the survivors) and k_extend (Scene::intersect).  Each gets its algorithmic
     # bytes per launch over its HIP-event launch time; `roofline` is the one with the largest share of the frame.
     roofline = None
+    traced_shadow_per_step = None
     if a.stats_spp > 0 and cnt["launches_shadow"] > 0:
         sp = params.copy()
         sp.spp = a.stats_spp
@@ -166,6 +188,7 @@ def main():
             # k_trace_p, per traced ray: 80 B per 8-wide node visited, 48 B per primitive record tested, 56 B of ray I/O
             # (32 B ray record + 16 B vertex position + 4 B flag read + 4 B flag write-back).  The rays k_light settles are not counted.
             traced_frac = ts["refill_lanes"] / n_shadow
+            traced_shadow_per_step = traced_frac * cnt["rays_shadow"]
             nodes_per_ray = ts["node_lanes"] / ts["refill_lanes"]
             prims_per_ray = ts["prim_lanes"] / ts["refill_lanes"]
             b_trace = 80.0 * nodes_per_ray + 48.0 * prims_per_ray + 56.0
@@ -180,9 +203,9 @@ def main():
                              "lanes_per_prim_step": round(ts["prim_lanes"] / max(ts["prim_steps"], 1), 1),
                              "lanes_per_refill": round(ts["refill_lanes"] / max(ts["refills"], 1), 1)}}
             # k_light, per light sample: the vertex record (position 16 B, normal 16 B, path slot 8 B, RNG state 8 B) is read once per
-            # vertex and serves nlL samples; every sample writes its (|cos|, pdf) pair (8 B) and 1/64 of a row mask (8 B); a ray left
-            # to trace also writes its 32-B record.
-            b_light = 48.0 / max(nlL, 1) + 8.0 + 8.0 / 64.0 + 32.0 * traced_frac
+            # vertex and serves nlL samples; every sample writes 1/64 of a row mask (8 B); a ray it cannot settle as blocked also writes
+            # its 32-B record (packed at the front of the row).
+            b_light = 48.0 / max(nlL, 1) + 8.0 / 64.0 + 32.0 * traced_frac
             kernels["k_light"] = {
                 "what": "Object::sample_l for every (vertex, light sample) + the test of the object the ray starts on + the per-light occluder cache",
                 "unit": "light sample", "bytes_per_unit": round(b_light, 2), "units_per_launch": round(cnt["rays_shadow"] / launches, 1),
@@ -210,7 +233,7 @@ def main():
             k["share_of_kernel_time"] = round(k["ms_per_step"] / max(frame_ms, 1e-9), 4)
             k["achieved_GBps"] = round(k["bytes_per_unit"] * k["units_per_launch"] / max(k["avg_launch_ms"], 1e-9) / 1e6, 2)
             k["frac_of_hbm_peak"] = round(k["achieved_GBps"] / HBM_PEAK_GBS, 5)
-            m = pmc.get(name, {})
+            m = pmc.get(name, {}) if isinstance(pmc.get(name, {}), dict) else {}
             k["traffic"] = m.get("hbm_bytes_per_launch")
             for f in ("l2_hit_rate", "valu_issue_busy", "valu_active_lanes", "valu_insts_per_launch"):
                 if f in m:
@@ -219,7 +242,7 @@ def main():
         d = kernels[dom]
         roofline = {
             "bound": "hbm", "achieved": d["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["frac_of_hbm_peak"],
-            "traffic": d["traffic"], "traffic_source": pmc.get("_source"),
+            "traffic": d["traffic"], "traffic_source": pmc.get("_source"), "traffic_note": pmc.get("_note"),
             "kernel": "%s (%s)" % (dom, d["what"]), "bytes_per_unit": d["bytes_per_unit"], "unit_of_work": d["unit"],
             "units_per_launch": d["units_per_launch"], "avg_launch_ms": d["avg_launch_ms"], "launches_per_step": d["launches_per_step"],
             "limiter": {"kind": "VALU issue", "valu_issue_busy": d.get("valu_issue_busy"), "valu_active_lanes": d.get("valu_active_lanes"),
@@ -246,36 +269,69 @@ def main():
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[3]: dragon GI, %dx%d, %d spp, %d light samples, depth %d, 32x32 screen tiles over %d GPU(s)%s"
-                   % (a.width, a.height, a.spp, a.light_samples, a.bounces, world, (" + RCCL all_gather" if backend == "nccl" else " + %s all_gather (rehearsal: ranks share devices)" % backend) if world > 1 else ""),
+                   % (a.width, a.height, a.spp, a.light_samples, a.bounces, world, (" + native RCCL all-gather (rt_gather_tiles)" if comm is not None or world == 1 else " + gloo all_gather through the host") if world > 1 else ""),
                    "mesh": "%s, %d triangles" % (mesh_label, n_tri - 10), "seed": a.seed, "scene_build_s": round(scene_s, 2)},
         "samples_per_s": round(samples * a.steps / elapsed, 1),
         "rays_per_step": int(rays_per_step), "rays_closest_per_step": int(rays_closest), "rays_shadow_per_step": int(rays_shadow),
         "rays_per_sample": round(rays_per_step / max(samples, 1), 2),
+        # the headline counts every Scene::intersect and Scene::is_occluded call, as SURVEY.md 8(d) defines a ray; most is_occluded calls are
+        # settled by the test of the object the ray starts on and the per-light occluder cache, without a tree search.  This is the rate of
+        # the rays that do search a tree (all intersect rays + the is_occluded rays k_trace_p traverses), world == 1 only.
+        "traversed_Mrays_per_s": (round((rays_closest + traced_shadow_per_step) * a.steps / elapsed / 1e6, 2) if traced_shadow_per_step is not None else None),
         "kernel_ms_last_step": {"trace_shadow": round(cnt["kernel_ms_shadow"], 2), "trace_closest": round(cnt["kernel_ms_closest"], 2),
                                 "light_sampling": round(cnt["kernel_ms_light"], 2), "shade_generate_resolve": round(cnt["kernel_ms_shade"], 2)},
         "roofline": roofline, "cpu_baseline": cpu,
     }
+    if gather_note:
+        out["gather_note"] = gather_note
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
 def pmc_kernels(a):
-    """Per-kernel PMC figures of the committed rocprofv3 passes (profiles/r01_pmc.json, written by tools/summarize_prof.py): HBM-side
+    """Per-kernel PMC figures of the newest committed rocprofv3 passes (profiles/r*_pmc.json, written by tools/summarize_prof.py): HBM-side
     bytes per launch from FETCH_SIZE / WRITE_SIZE (own passes, corrected as MI355X_MICROARCH.md prescribes), L2 hit rate, VALU issue
-    utilisation.  bench.py cannot collect PMC counters on itself; the figures are only reported for the workload they were measured on."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc.json")
+    utilisation.  bench.py cannot collect PMC counters on itself, so the figures are reported only for the workload AND the kernel sources
+    they were measured on: each file carries the hash of the device sources at profile time, and a file whose hash differs from the
+    running tree's is ignored (`traffic` null, with a note)."""
+    import glob
+    from rustracer_amd._lib import kernel_source_hash
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    if not paths:
+        return {"_note": "no profiles/r*_pmc.json"}
+    path = paths[-1]
     try:
         with open(path) as f:
             j = json.load(f)
     except (OSError, ValueError):
-        return {}
+        return {"_note": "%s unreadable" % os.path.basename(path)}
     w = j.get("workload", {})
     if (w.get("width"), w.get("height"), w.get("light_samples"), w.get("bounces"), w.get("mesh")) != (a.width, a.height, a.light_samples, a.bounces, a.mesh):
-        return {}
+        return {"_note": "%s was measured on another workload" % os.path.basename(path)}
+    if j.get("kernel_source_hash") != kernel_source_hash():
+        return {"_note": "%s was measured on other kernel sources (hash %s at commit %s, running %s): PMC figures withheld"
+                         % (os.path.basename(path), j.get("kernel_source_hash"), j.get("git_commit"), kernel_source_hash())}
     out = dict(j.get("kernels", {}))
-    out["_source"] = "profiles/r01_pmc.json (%s)" % j.get("source", "")
+    out["_source"] = "profiles/%s (%s; commit %s)" % (os.path.basename(path), j.get("source", ""), j.get("git_commit"))
     return out
+
+
+def host_cpus():
+    """CPUs this process may really use: its affinity mask, cut by the cgroup CPU quota and by OMP_NUM_THREADS when the box sets one
+    (the GPU boxes of this pool expose every core of the machine to a job whose share is 16)."""
+    affinity = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+            if q != "max":
+                quota = max(int(-(-int(q) // int(per))), 1)
+    except (OSError, ValueError):
+        pass
+    omp = int(os.environ.get("OMP_NUM_THREADS", "0")) or None
+    use = min(v for v in (affinity, quota, omp) if v)
+    return use, {"os_cpu_count": os.cpu_count(), "sched_getaffinity": affinity, "cgroup_quota": quota, "OMP_NUM_THREADS": omp}
 
 
 def cpu_baseline(a, standin, dragon_obj, target_s):
@@ -283,7 +339,7 @@ def cpu_baseline(a, standin, dragon_obj, target_s):
     (shard 0 of `stride`) at reduced spp, sized to about `target_s` seconds."""
     from oracle import binding as ob
     import rustracer_amd as ra
-    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    cores, cpu_info = host_cpus()
     if standin is not None:
         vp, vn, f = ra.dragon_standin_mesh(*standin)
         osc = ob.OracleScene.dragon_mesh(vp, vn, f)
@@ -312,7 +368,7 @@ def cpu_baseline(a, standin, dragon_obj, target_s):
         stride = 1
         spp = int(min(a.spp, max(spp, want_tile_spp // n_tiles)))
     rays, dt = run(stride)
-    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port", "host_cpus": cpu_info,
             "sample": "oracle (C++ restatement of the reference algorithm, %d threads): every %d-th 32x32 tile of the same %dx%d frame at %d spp, "
                       "%d light samples, depth %d: %d rays in %.1f s" % (cores, stride, a.width, a.height, spp, a.light_samples, a.bounces, rays, dt)}
 

@@ -160,6 +160,24 @@ int rt_tiles_pack(const rt_render_params* params, const void* frame_dev, void* c
 int rt_tiles_unpack(const rt_render_params* params, uint32_t shard_index, const void* compact_dev, void* frame_dev,
                     uint32_t bytes_per_pixel, void* stream);
 
+/* Multi-GPU frame (no reference counterpart): one process per GPU, rank r renders the tiles t with t % world == r
+ * (rt_render_device with shard_index = r, shard_count = world) and ONE collective completes the frame on every rank:
+ * rt_gather_tiles = rt_tiles_pack -> ncclAllGather (RCCL over xGMI) -> rt_tiles_unpack of every rank's tiles, all on `stream`,
+ * no host synchronisation, no allocation after the first frame of a geometry.  The communicator is made from a 128-byte RCCL
+ * unique id that rank 0 creates (rt_comm_unique_id) and the caller distributes by whatever it has (a file, MPI, a torch
+ * process group); rt_comm_init_rank is collective over the `world` ranks and uses the GPU chosen by rt_init.  The consumer of
+ * the gathered frame is Canvas (src/canvas.rs:88-110). */
+typedef struct rt_comm rt_comm;
+int rt_comm_unique_id(uint8_t* id128);
+int rt_comm_init_rank(const uint8_t* id128, int world, int rank, rt_comm** out);
+void rt_comm_destroy(rt_comm* comm);
+int rt_gather_tiles(rt_comm* comm, const rt_render_params* params, void* frame_dev, uint32_t bytes_per_pixel, void* stream);
+/* rt_render for one rank of a multi-GPU job: renders this rank's shard (params->shard_index / shard_count must be the communicator's
+ * rank / world), gathers every rank's tiles on the device and copies the complete frame to host memory on every rank.  Collective:
+ * every rank must call it for every frame, interrupted or not.  comm == NULL is rt_render. */
+int rt_render_comm(rt_scene* scene, const rt_render_params* params, rt_comm* comm, uint8_t* rgba,
+                   volatile uint32_t* progress, const volatile uint32_t* interrupt);
+
 /* ---- host-side helpers mirroring the reference's scene constructors ---- */
 /* ScreenParams::from_config (src/raytracer.rs:110-124); fills width..z of *params. */
 void rt_screen_params(uint32_t width, uint32_t height, float fov_radians, rt_render_params* params);

@@ -65,7 +65,7 @@ class Counters(C.Structure):
 EXPORTS = [
     "rt_last_error", "rt_init", "rt_scene_create", "rt_scene_destroy", "rt_scene_info_get", "rt_scene_lights", "rt_scene_bvh", "rt_scene_wide_bvh",
     "rt_render", "rt_render_device", "rt_cast_primary", "rt_cast_primary_device", "rt_cast_primary_noalloc", "rt_intersect_rays", "rt_occluded_rays",
-    "rt_get_counters", "rt_set_option", "rt_tiles_per_shard", "rt_tiles_pack", "rt_tiles_unpack", "rt_screen_params",
+    "rt_get_counters", "rt_set_option", "rt_tiles_per_shard", "rt_tiles_pack", "rt_tiles_unpack", "rt_comm_unique_id", "rt_comm_init_rank", "rt_comm_destroy", "rt_gather_tiles", "rt_render_comm", "rt_screen_params",
     "rt_scene_new_named", "rt_scene_new_dragon_mesh", "rt_scene_export", "rt_make_dragon_standin", "rt_debug_math", "rt_debug_rng", "rt_debug_exact",
 ]
 
@@ -110,6 +110,12 @@ def lib():
     L.rt_tiles_per_shard.restype = u32
     L.rt_tiles_pack.argtypes = [C.POINTER(RenderParams), vp, vp, u32, vp]
     L.rt_tiles_unpack.argtypes = [C.POINTER(RenderParams), u32, vp, vp, u32, vp]
+    L.rt_comm_unique_id.argtypes = [vp]
+    L.rt_comm_init_rank.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
+    L.rt_comm_destroy.argtypes = [vp]
+    L.rt_comm_destroy.restype = None
+    L.rt_gather_tiles.argtypes = [vp, C.POINTER(RenderParams), vp, u32, vp]
+    L.rt_render_comm.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, vp]
     L.rt_screen_params.argtypes = [u32, u32, f32, C.POINTER(RenderParams)]
     L.rt_screen_params.restype = None
     L.rt_scene_new_named.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(vp)]
@@ -121,6 +127,17 @@ def lib():
     L.rt_debug_rng.argtypes = [u64, u32, u32, u32, vp]
     _lib = L
     return L
+
+
+def kernel_source_hash():
+    """sha256 over the sources the device code is built from: stamps profiles (tools/profile.sh) so that bench.py can tell whether
+    committed PMC figures were measured on the kernels it is running."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("rt_kernels.h", "rt_math.h", "rt_api.hip", "host_scene.h", "Makefile"):
+        with open(os.path.join(_HERE, "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def check(rc):

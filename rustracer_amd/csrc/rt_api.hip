@@ -1,6 +1,7 @@
 // rt_api.hip — implementation of the C ABI in include/rustracer_hip.h: scene upload, pass
 // scheduling of the wavefront kernels (rt_kernels.h) and the debug probes.  gfx950 only.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -87,6 +88,8 @@ struct EventPair {
 
 }  // namespace
 
+struct rt_comm;
+
 struct rt_scene {
     int device = 0;   // the GPU this scene lives on (g_device when it was created)
     HostScene host;
@@ -167,6 +170,44 @@ void record_box(const float* q, float* mn, float* mx) {
         }
     } else {
         for (int a = 0; a < 3; ++a) { mn[a] = q[a] - q[4]; mx[a] = q[a] + q[4]; }
+    }
+}
+
+// Ill-conditioned triangles (rt_kernels.h prune_limit): the sine of the angle between the edges below 2^-5, or not a number.  The distance
+// their test returns can be far from the true one for any ray, and the reference's unpruned search accepts it; the kernels therefore do not
+// skip subtrees that hold one.  frag_obj[object]; *inner[node] bit 0 / 1 = left / right subtree holds one; *wide[node] = the 8-wide node does.
+void mark_fragile(const rt_scene* s, std::vector<uint8_t>* frag_obj, std::vector<uint8_t>* inner, std::vector<uint8_t>* wide) {
+    const HostScene& h = s->host;
+    const uint32_t T = h.n_tri(), n_obj = T + h.n_sph();
+    frag_obj->assign(n_obj, 0);
+    for (uint32_t i = 0; i < T; ++i) {
+        const float* p = &h.tri_pos[9 * (size_t)i];
+        double e1[3], e2[3];
+        for (int k = 0; k < 3; ++k) { e1[k] = (double)p[3 + k] - (double)p[k]; e2[k] = (double)p[6 + k] - (double)p[k]; }
+        const double cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+        const double c2 = cx * cx + cy * cy + cz * cz, l1 = e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2], l2 = e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2];
+        if (!(c2 >= (1.0 / 1024.0) * l1 * l2) || !(l1 * l2 > 0.0) || !(l1 * l2 < 1e300)) (*frag_obj)[i] = 1;   // sin^2 < 2^-10, zero area, non-finite
+    }
+    const FlatBVH& b = s->bvh;
+    const uint32_t ni = b.n_inner();
+    inner->assign(ni, 0);
+    auto ref_fragile = [&](uint32_t ref) -> bool { return (ref & LEAF_BIT) ? (*frag_obj)[ref & OBJECT_MASK] != 0 : (*inner)[ref] != 0; };
+    for (uint32_t i = ni; i-- > 0;) {   // pre-order: children have larger indices
+        const uint32_t* w = &b.words[16 * (size_t)i];
+        (*inner)[i] = (uint8_t)((ref_fragile(w[12]) ? 1 : 0) | (ref_fragile(w[13]) ? 2 : 0));
+    }
+    const WideBVH& wd = s->wide;
+    wide->assign(wd.ok ? wd.n_nodes() : 0, 0);
+    for (uint32_t i = (uint32_t)wide->size(); i-- > 0;) {   // breadth-first: children have larger indices
+        const uint32_t* q = &wd.nodes[20 * (size_t)i];
+        const uint32_t n_inner = (q[3] >> 24) & 0xFu, n_child = q[3] >> 28;
+        uint8_t f = 0;
+        for (uint32_t k = 0; k < n_inner; ++k) f |= (*wide)[q[4] + k];
+        for (uint32_t k = 0; k < n_child - n_inner; ++k) {
+            const float* r = &wd.prims[12 * (size_t)(q[5] + k)];
+            if (float_to_bits(r[3]) == 0u) f |= (*frag_obj)[float_to_bits(r[7])];
+        }
+        (*wide)[i] = f;
     }
 }
 
@@ -256,6 +297,8 @@ int upload_scene(rt_scene* s) {
         mats[2 * (size_t)i + 1] = make_float4(m.emittance[0], m.emittance[1], m.emittance[2], 0.0f);
     }
     const size_t n_inner = b.n_inner();
+    std::vector<uint8_t> frag_obj, frag_inner, frag_wide;
+    mark_fragile(s, &frag_obj, &frag_inner, &frag_wide);
     int rc;
     if ((rc = s->d_nodes.ensure(4 * (n_inner ? n_inner : 1)))) return rc;
     if ((rc = s->d_tris.ensure(tris.size() ? tris.size() : 1))) return rc;
@@ -267,15 +310,20 @@ int upload_scene(rt_scene* s) {
     if (s->wide.ok) {
         if ((rc = s->d_wnodes.ensure(5 * (size_t)s->wide.n_nodes()))) return rc;
         if ((rc = s->d_wprims.ensure(3 * (size_t)s->wide.n_prims()))) return rc;
-        HIP_TRY(hipMemcpy(s->d_wnodes.p, s->wide.nodes.data(), s->wide.nodes.size() * 4, hipMemcpyHostToDevice));
+        {
+            std::vector<uint32_t> wn(s->wide.nodes);   // device copy: word 6 = the node holds an ill-conditioned triangle
+            for (size_t i = 0; i < frag_wide.size(); ++i) wn[20 * i + 6] = frag_wide[i];
+            HIP_TRY(hipMemcpy(s->d_wnodes.p, wn.data(), wn.size() * 4, hipMemcpyHostToDevice));
+        }
         HIP_TRY(hipMemcpy(s->d_wprims.p, s->wide.prims.data(), s->wide.prims.size() * 4, hipMemcpyHostToDevice));
         if ((rc = s->d_wrec.ensure(s->wide.rec_of_obj.size()))) return rc;
         HIP_TRY(hipMemcpy(s->d_wrec.p, s->wide.rec_of_obj.data(), s->wide.rec_of_obj.size() * 4, hipMemcpyHostToDevice));
     }
     if (ovf_rows && (rc = s->d_ovf.ensure((size_t)ovf_rows * s->grid_max * RT_BLOCK))) return rc;
     if (n_inner) {
-        // device copy of the nodes: leaves of emissive objects carry NONBLOCK_BIT
+        // device copy of the nodes: leaves of emissive objects carry NONBLOCK_BIT, word 14 the FRAGILE bits of the two subtrees
         std::vector<uint32_t> words(b.words);
+        for (size_t i = 0; i < n_inner; ++i) words[16 * i + 14] = frag_inner[i];
         for (size_t i = 0; i < n_inner; ++i)
             for (int c = 12; c <= 13; ++c) {
                 const uint32_t ref = words[16 * i + c];
@@ -765,18 +813,29 @@ int rt_render_device(rt_scene* s, const rt_render_params* params, void* rgba_dev
     return render_impl(s, params, (uint8_t*)rgba_dev, (hipStream_t)stream, nullptr, nullptr);
 }
 
-int rt_render(rt_scene* s, const rt_render_params* params, uint8_t* rgba, volatile uint32_t* progress, const volatile uint32_t* interrupt) {
+int rt_gather_tiles(rt_comm* c, const rt_render_params* P, void* frame_dev, uint32_t bytes_per_pixel, void* stream);
+
+int rt_render_comm(rt_scene* s, const rt_render_params* params, rt_comm* comm, uint8_t* rgba, volatile uint32_t* progress, const volatile uint32_t* interrupt) {
     if (!s || !rgba) return fail(RT_ERR_INVALID, "NULL argument");
     int rc;
     if ((rc = validate_params(params))) return rc;
     BIND(s->device);
     const size_t bytes = (size_t)params->width * params->height * 4;
     if ((rc = s->w_frame.ensure(bytes))) return rc;
-    HIP_TRY(hipMemcpy(s->w_frame.p, rgba, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->w_frame.p, rgba, bytes, hipMemcpyHostToDevice));   // pixels of other shards / of an interrupted render stay as the caller has them
     rc = render_impl(s, params, s->w_frame.p, nullptr, progress, interrupt);
+    // every rank takes part in the collective, interrupted or not: a rank that skipped it would leave the others waiting
+    if (comm && (rc == RT_OK || rc == RT_ERR_INTERRUPTED)) {
+        const int rg = rt_gather_tiles(comm, params, s->w_frame.p, 4, nullptr);
+        if (rg) rc = rg;
+    }
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(rgba, s->w_frame.p, bytes, hipMemcpyDeviceToHost));   // partial pixels stay in the buffer on interrupt
     return rc;
+}
+
+int rt_render(rt_scene* s, const rt_render_params* params, uint8_t* rgba, volatile uint32_t* progress, const volatile uint32_t* interrupt) {
+    return rt_render_comm(s, params, nullptr, rgba, progress, interrupt);
 }
 
 int rt_cast_primary_device(rt_scene* s, const rt_render_params* params, void* ids_dev, void* t_dev, void* stream) {
@@ -958,6 +1017,76 @@ int rt_tiles_unpack(const rt_render_params* P, uint32_t shard_index, const void*
     hipLaunchKernelGGL(k_tiles_copy, dim3((uint32_t)g), dim3(256), 0, (hipStream_t)stream, *P, tiles_x, shard_index, slots,
                        (const uint32_t*)compact_dev, (uint32_t*)frame_dev, bytes_per_pixel / 4, 1);
     HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+// ---- multi-GPU: the frame's screen tiles over RCCL ----
+}  // extern "C"
+
+struct rt_comm {
+    ncclComm_t comm = nullptr;
+    int world = 1, rank = 0, device = 0;
+    DevBuf<uint8_t> send, recv;   // compact tiles of this rank / of every rank; grow-only: no allocation per frame once sized
+};
+
+namespace {
+#define NCCL_TRY(expr)                                                                                       \
+    do {                                                                                                     \
+        ncclResult_t r_ = (expr);                                                                            \
+        if (r_ != ncclSuccess) return fail(RT_ERR_HIP, std::string(#expr) + ": " + ncclGetErrorString(r_));  \
+    } while (0)
+}  // namespace
+
+extern "C" {
+
+int rt_comm_unique_id(uint8_t* id128) {
+    if (!id128) return fail(RT_ERR_INVALID, "NULL argument");
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    NCCL_TRY(ncclGetUniqueId(&id));
+    memcpy(id128, &id, 128);
+    return RT_OK;
+}
+
+int rt_comm_init_rank(const uint8_t* id128, int world, int rank, rt_comm** out) {
+    if (!id128 || !out) return fail(RT_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world) return fail(RT_ERR_INVALID, "bad world size or rank");
+    BIND(g_device);
+    ncclUniqueId id;
+    memcpy(&id, id128, 128);
+    rt_comm* c = new rt_comm();
+    c->world = world; c->rank = rank; c->device = g_device;
+    const ncclResult_t r = ncclCommInitRank(&c->comm, world, id, rank);
+    if (r != ncclSuccess) { delete c; return fail(RT_ERR_HIP, std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); }
+    *out = c;
+    return RT_OK;
+}
+
+void rt_comm_destroy(rt_comm* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    if (c->comm) (void)ncclCommDestroy(c->comm);
+    c->send.release(); c->recv.release();
+    delete c;
+}
+
+int rt_gather_tiles(rt_comm* c, const rt_render_params* P, void* frame_dev, uint32_t bytes_per_pixel, void* stream) {
+    if (!c || !frame_dev) return fail(RT_ERR_INVALID, "NULL argument");
+    int rc;
+    if ((rc = validate_params(P))) return rc;
+    if (bytes_per_pixel == 0 || bytes_per_pixel % 4) return fail(RT_ERR_INVALID, "bytes_per_pixel must be a multiple of 4");
+    if (P->shard_count != (uint32_t)c->world || P->shard_index != (uint32_t)c->rank)
+        return fail(RT_ERR_INVALID, "params name shard " + std::to_string(P->shard_index) + " of " + std::to_string(P->shard_count) + " but the communicator is rank " +
+                                    std::to_string(c->rank) + " of " + std::to_string(c->world));
+    BIND(c->device);
+    const size_t bytes = (size_t)rt_tiles_per_shard(P) * P->tile_w * P->tile_h * bytes_per_pixel;   // equal on every rank (padded)
+    if ((rc = c->send.ensure(bytes)) || (rc = c->recv.ensure(bytes * (size_t)c->world))) return rc;   // first frame of a geometry only
+    if ((rc = rt_tiles_pack(P, frame_dev, c->send.p, bytes_per_pixel, stream))) return rc;
+    NCCL_TRY(ncclAllGather(c->send.p, c->recv.p, bytes, ncclUint8, c->comm, (hipStream_t)stream));
+    for (int r = 0; r < c->world; ++r)
+        if ((rc = rt_tiles_unpack(P, (uint32_t)r, c->recv.p + bytes * (size_t)r, frame_dev, bytes_per_pixel, stream))) return rc;
     return RT_OK;
 }
 

@@ -302,7 +302,13 @@ __device__ __forceinline__ float hi3(float a, float b, float c) { const float m 
 
 // Pruning slack: a subtree is skipped only when its entry distance exceeds the current limit by
 // more than 2^-10 relative (absolute below 1).  The primitive's own t and the box entry are
-// rounded differently; the slack keeps the winner identical to the reference's unpruned search.
+// rounded differently; the slack keeps the winner identical to the reference's unpruned search
+// as long as the triangle test returns a distance within 2^-11 of the true one.  It does not for
+// ill-conditioned triangles (slivers: |e1 x e2| < 2^-5 |e1| |e2|, where 1 / (s1 . e1) loses its
+// leading bits for every ray; the reference accepts whatever distance comes out, mod.rs:436-441):
+// subtrees that hold one are flagged at upload (FRAGILE bits, rt_api.hip mark_fragile) and never
+// skipped.  What remains is a ray that runs within about 1e-3 rad of the plane of a well-shaped
+// triangle beyond its best hit and still passes the triangle's box.
 __device__ __forceinline__ float prune_limit(float t) { return t + fmaxf(fabsf(t), 1.0f) * (1.0f / 1024.0f); }
 
 // BVH traversal, one ray per lane, executed by the whole wave in step ("while-while"): lanes walk
@@ -378,9 +384,9 @@ __device__ __forceinline__ void traverse(const DevScene& sc, bool have_ray, vec3
                 bool hl = slab(br, a.x, a.y, a.z, a.w, b.x, b.y, &tl);
                 bool hr = slab(br, b.z, b.w, c.x, c.y, c.z, c.w, &tr);
                 const float lim = KIND == 0 ? prune_limit(best) : lim_any;
-                hl = hl && !(tl > lim);
-                hr = hr && !(tr > lim);
-                const uint32_t left = __float_as_uint(k.x), right = __float_as_uint(k.y);
+                const uint32_t left = __float_as_uint(k.x), right = __float_as_uint(k.y), fragile = __float_as_uint(k.z);
+                hl = hl && (!(tl > lim) || (fragile & 1u));      // a subtree holding an ill-conditioned triangle is searched like the reference does: unpruned
+                hr = hr && (!(tr > lim) || (fragile & 2u));
                 if (hl && hr) {
                     const bool left_first = !(tr < tl);
                     st.push(left_first ? right : left);
@@ -542,7 +548,7 @@ __device__ __forceinline__ void wide_node_step(const DevScene& sc, const BoxRay&
     const float4* np = sc.wnodes + 5 * (size_t)node;
     const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
     if (STATS) ts->wide++;
-    const uint32_t hm = wide_child_mask(br, lim, n0, n2, n3, n4);
+    const uint32_t hm = wide_child_mask(br, __float_as_uint(n1.z) ? __builtin_inff() : lim, n0, n2, n3, n4);   // n1.z: the node holds an ill-conditioned triangle (see prune_limit)
     uint32_t a, b;
     wide_groups(hm, __float_as_uint(n0.w), __float_as_uint(n1.x), __float_as_uint(n1.y), skip_rec, &a, &b);   // primitives first: a blocker ends the ray
     uint32_t c = rest;

@@ -7,10 +7,15 @@
 
 #include <chrono>
 #include <string>
+#include <thread>
 
 #include "rustracer.hpp"
 
 using namespace rustracer;
+
+static void check(int rc) {
+    if (rc != RT_OK) throw Error(rc, rt_last_error());
+}
 
 static int usage(FILE* f) {
     fprintf(f,
@@ -28,7 +33,9 @@ static int usage(FILE* f) {
             "    -w <w>        Screen width\n"
             "        --seed <n>     RNG seed (the reference is time-seeded)\n"
             "        --obj-dir <d>  Directory holding teapot.obj / dragon.obj (default: obj)\n\n"
-            "ENVIRONMENT:\n    SCENE   dragon | teapot | specular (default) | diffuse | triangle | sphere_on_plane | specular_teapot\n");
+            "ENVIRONMENT:\n    SCENE   dragon | teapot | specular (default) | diffuse | triangle | sphere_on_plane | specular_teapot\n"
+            "    WORLD_SIZE, RANK, LOCAL_RANK, RT_COMM_ID_FILE   one process per GPU: rank r renders the screen tiles t %% world == r, the tiles are\n"
+            "            gathered over RCCL and rank 0 writes the PNG; RT_COMM_ID_FILE is a path all ranks share (rank 0 writes the RCCL id there)\n");
     return f == stdout ? 0 : 2;
 }
 
@@ -71,11 +78,41 @@ int main(int argc, char** argv) {
         Scene scene = Scene::by_name(scene_name, config.obj_dir);
         printf("Scene '%s' loaded in %.3fs\n", scene_name.c_str(), std::chrono::duration<double>(std::chrono::steady_clock::now() - load_start).count());
         Raytracer raytracer = Raytracer::new_(config, std::move(scene));
+        // one process per GPU (no reference counterpart)
+        const int world = getenv("WORLD_SIZE") ? atoi(getenv("WORLD_SIZE")) : 1, rank = getenv("RANK") ? atoi(getenv("RANK")) : 0;
+        rt_comm* comm = nullptr;
+        if (world > 1 || getenv("RT_COMM_ID_FILE")) {
+            const char* path = getenv("RT_COMM_ID_FILE");
+            if (!path) throw Error(RT_ERR_INVALID, "WORLD_SIZE > 1 needs RT_COMM_ID_FILE (a path every rank can read)");
+            uint8_t id[128];
+            if (rank == 0) {
+                check(rt_comm_unique_id(id));
+                const std::string tmp = std::string(path) + ".tmp";
+                FILE* f = fopen(tmp.c_str(), "wb");
+                if (!f || fwrite(id, 1, 128, f) != 128) throw Error(RT_ERR_INVALID, "cannot write RT_COMM_ID_FILE");
+                fclose(f);
+                if (rename(tmp.c_str(), path)) throw Error(RT_ERR_INVALID, "cannot publish RT_COMM_ID_FILE");
+            } else {
+                bool got = false;
+                for (int tries = 0; tries < 6000 && !got; ++tries) {   // up to a minute
+                    if (FILE* f = fopen(path, "rb")) {
+                        got = fread(id, 1, 128, f) == 128;
+                        fclose(f);
+                    }
+                    if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+                }
+                if (!got) throw Error(RT_ERR_INVALID, "RT_COMM_ID_FILE did not appear");
+            }
+            check(rt_comm_init_rank(id, world, rank, &comm));
+            raytracer.set_shard((uint32_t)rank, (uint32_t)world, comm);
+            raytracer.inner->canvas.save = rank == 0;
+        }
         if (config.debug) {
             // `-d` is parsed but unused by the reference (Config.debug, src/main.rs:28); here it prints the centre pixel's debug colour
             raytracer.inner->test(config.screen_width / 2, config.screen_height / 2);
         }
         raytracer.start();
+        if (comm) rt_comm_destroy(comm);
         return 0;
     } catch (const Error& e) {
         fprintf(stderr, "%s\n", e.what());

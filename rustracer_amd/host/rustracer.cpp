@@ -188,13 +188,13 @@ void RaytracerInner::render_mode(RenderingMode mode) {
     }
     p.cam[0] = cam.x; p.cam[1] = cam.y; p.cam[2] = cam.z;
     p.mode = mode == RenderingMode::Full ? RT_MODE_FULL : RT_MODE_DEBUG;
-    p.tile_w = 32; p.tile_h = 32; p.shard_index = 0; p.shard_count = 1;
+    p.tile_w = 32; p.tile_h = 32; p.shard_index = shard_index; p.shard_count = shard_count;   // one process per GPU: this rank's screen tiles
     int rc;
     {
         std::shared_lock<std::shared_mutex> g(scene_lock);   // read-held for the whole render, raytracer.rs:176
         uint32_t progress_word = 0;
         // the library writes progress through a plain word; mirror it into the atomic the canvas polls
-        rc = rt_render(scene.handle(), &p, pixel_buffer->raw(), mode == RenderingMode::Full ? reinterpret_cast<volatile uint32_t*>(&render_progress) : &progress_word,
+        rc = rt_render_comm(scene.handle(), &p, comm, pixel_buffer->raw(), mode == RenderingMode::Full ? reinterpret_cast<volatile uint32_t*>(&render_progress) : &progress_word,
                        reinterpret_cast<const volatile uint32_t*>(&interrupt));
     }
     is_rendering.store(false);
@@ -241,6 +241,13 @@ Raytracer Raytracer::new_(const Config& config, Scene scene) {
     Raytracer r;
     r.inner = std::make_shared<RaytracerInner>(config, std::move(scene));
     return r;
+}
+void Raytracer::set_shard(uint32_t rank, uint32_t world, rt_comm* comm) {
+    // no reference counterpart: this process renders the tiles t % world == rank and every frame ends with one RCCL gather
+    if (world == 0 || rank >= world || (world > 1 && !comm)) throw Error(RT_ERR_INVALID, "bad shard description");
+    inner->shard_index = rank;
+    inner->shard_count = world;
+    inner->comm = comm;
 }
 void Raytracer::start() {
     if (!inner->canvas.image_mode) render(false);   // raytracer.rs:469-471
@@ -314,7 +321,7 @@ void Canvas::start_image_mode(const std::shared_ptr<RaytracerInner>& raytracer_i
     printf("Render time: %.3fs\n", elapsed);
     std::vector<uint8_t> rgba((size_t)width_ * height_ * 4);
     raytracer_inner->pixel_buffer->snapshot(rgba);
-    save_canvas(rgba_to_rgb(rgba, width_, height_));
+    if (save) save_canvas(rgba_to_rgb(rgba, width_, height_));
 }
 std::vector<uint8_t> Canvas::rgba_to_rgb(const std::vector<uint8_t>& rgba, uint32_t width, uint32_t height) {
     const size_t pixel_count = (size_t)width * height;

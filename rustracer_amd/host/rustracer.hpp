@@ -114,6 +114,7 @@ class Canvas {
     void start(const std::shared_ptr<RaytracerInner>& raytracer_inner);
     bool image_mode;
     std::string last_path;   // the file save_canvas wrote
+    bool save = true;        // multi-GPU: every rank holds the gathered frame, rank 0 writes it
     bool high_dpi() const { return high_dpi_; }   // only the window uses it (src/canvas.rs:113-449)
 
   private:
@@ -142,6 +143,8 @@ class RaytracerInner {
     void debug_render();    // raytracer.rs:353
     void test(uint32_t i, uint32_t j);   // raytracer.rs:419-428: prints one pixel's debug colour
     bool last_render_interrupted = false;
+    uint32_t shard_index = 0, shard_count = 1;   // multi-GPU: this process's share of the screen tiles (Raytracer::set_shard)
+    rt_comm* comm = nullptr;                      // RCCL communicator of the job (not owned)
 
     // used by Raytracer
     std::mutex config_mutex;
@@ -158,6 +161,7 @@ class RaytracerInner {
 class Raytracer {
   public:
     static Raytracer new_(const Config& config, Scene scene);
+    void set_shard(uint32_t rank, uint32_t world, rt_comm* comm);
     void start();
     void move_camera(Vector direction);           // x CAMERA_SPEED, raytracer.rs:18, 477-481
     void reset_camera();

@@ -7,8 +7,41 @@ tests) moves every rank's tiles to all ranks, where they are scattered into the 
 (`Canvas` reads rank 0's).  The RNG streams are keyed by the global pixel index, so the image does
 not depend on the number of ranks.
 """
+import ctypes as C
+
 import numpy as np
 import torch
+
+
+class Comm:
+    """RCCL communicator of the native gather (rt_comm_*, include/rustracer_hip.h): one per process, made from a 128-byte unique id
+    that rank 0 creates and `broadcast` (a callable: bytes-or-None -> bytes, e.g. over a gloo process group or a file) hands to
+    every rank.  gather(params, frame_ptr, stream) = pack -> ncclAllGather -> unpack on the stream, nothing else."""
+
+    def __init__(self, world, rank, broadcast):
+        from ._lib import check, lib
+        self.world, self.rank = world, rank
+        ident = None
+        if rank == 0:
+            buf = (C.c_uint8 * 128)()
+            check(lib().rt_comm_unique_id(buf))
+            ident = bytes(buf)
+        ident = broadcast(ident)
+        if not isinstance(ident, (bytes, bytearray)) or len(ident) != 128:
+            raise RuntimeError("the RCCL unique id did not arrive (got %r)" % (type(ident),))
+        h = C.c_void_p()
+        check(lib().rt_comm_init_rank((C.c_uint8 * 128).from_buffer_copy(ident), world, rank, C.byref(h)))
+        self._h = h
+
+    def gather(self, params, frame_ptr, stream, bytes_per_pixel=4):
+        from ._lib import check, lib
+        check(lib().rt_gather_tiles(self._h, C.byref(params), frame_ptr, bytes_per_pixel, stream))
+
+    def destroy(self):
+        from ._lib import lib
+        if self._h:
+            lib().rt_comm_destroy(self._h)
+            self._h = C.c_void_p()
 
 
 def tiles_per_shard(width, height, tile_w, tile_h, world):

@@ -572,6 +572,50 @@ def test_baseline_configs_at_full_resolution(scenes, name, w, h, spp, L, b, est,
         assert cnt["rays_closest"] == ref["intersect_calls"] and cnt["rays_shadow"] == ref["occluded_calls"]
 
 
+def _own_tiles(w, h, K):
+    tiles_x = (w + 31) // 32
+    return [((t % tiles_x) * 32, (t // tiles_x) * 32) for t in range(0, tiles_x * ((h + 31) // 32), K)]
+
+
+def test_config4_at_its_full_spp_on_strided_tiles(full_dragon):
+    """BASELINE config 4 exactly as stated (1920x1080, 256 spp, 32 light samples, depth 8) on every 97th 32x32 tile: both sides render
+    shard (0, 97) of the frame, so every sample index 0..255 and the accumulation across sample chunks (k_resolve's s0 > 0 path) are
+    compared at full size.  RGBA8 bit-identical, ray counts equal; once in one pass per chunk of the default size, once cut into >= 4
+    sample chunks."""
+    osc, gsc = full_dragon
+    W, H, K = 1920, 1080, 97
+    op = oracle_params(width=W, height=H, spp=256, light_samples=32, bounces=8, seed=0x5EED, tile=(32, 32), shard=(0, K))
+    ref = osc.render(op)
+    tiles = _own_tiles(W, H, K)
+    n_pix = sum(min(32, W - x0) * min(32, H - y0) for x0, y0 in tiles)
+    for max_paths in (0, n_pix * 50):                      # default pass size; then 50 of the 256 samples per pass: 6 chunks, the last one short
+        gsc.set_option("max_paths", max_paths)
+        got, cnt = gpu_render(gsc, to_rt_params(op))
+        gsc.set_option("max_paths", 0)
+        assert cnt["samples"] == n_pix * 256
+        assert cnt["rays_closest"] == ref["intersect_calls"] and cnt["rays_shadow"] == ref["occluded_calls"]
+        for x0, y0 in tiles:
+            a, b = got[y0:y0 + 32, x0:x0 + 32], ref["rgba"][y0:y0 + 32, x0:x0 + 32]
+            assert np.array_equal(a, b), "tile at (%d, %d): %d bytes differ (max_paths %d)" % (x0, y0, int((a != b).sum()), max_paths)
+    assert len(tiles) >= 20
+
+
+def test_config5_at_its_full_spp_on_strided_tiles(scenes):
+    """BASELINE config 5 exactly as stated (3840x2160, 1024 spp, 32 light samples, depth 8, spheres + teapot) on every 1600th tile."""
+    osc, gsc = scenes("specular_teapot")
+    W, H, K = 3840, 2160, 1600
+    op = oracle_params(width=W, height=H, spp=1024, light_samples=32, bounces=8, seed=0x5EED, tile=(32, 32), shard=(0, K))
+    ref = osc.render(op)
+    got, cnt = gpu_render(gsc, to_rt_params(op))
+    tiles = _own_tiles(W, H, K)
+    assert cnt["samples"] == sum(min(32, W - x0) * min(32, H - y0) for x0, y0 in tiles) * 1024
+    assert cnt["rays_closest"] == ref["intersect_calls"] and cnt["rays_shadow"] == ref["occluded_calls"]
+    for x0, y0 in tiles:
+        a, b = got[y0:y0 + 32, x0:x0 + 32], ref["rgba"][y0:y0 + 32, x0:x0 + 32]
+        assert np.array_equal(a, b), "tile at (%d, %d): %d bytes differ" % (x0, y0, int((a != b).sum()))
+    assert len(tiles) >= 5
+
+
 def test_degenerate_scenes_and_frames(gpu):
     """Empty object list, a lamp alone (no blocker: no occlusion BVH), one wall under a lamp, a 1x1 frame and a frame whose size is no
     multiple of the screen tile: images and ray counts equal the oracle's."""
@@ -684,3 +728,114 @@ def test_fast_ieee_forms_are_exact(gpu, op, what):
     out = np.zeros(2, np.uint64)
     check(lib().rt_debug_exact(op, out.ctypes.data_as(C.c_void_p)))
     assert out[0] == 0, "%s: %d inputs differ, e.g. 0x%x" % (what, int(out[0]), int(out[1]))
+
+
+def _oracle_intersect_parallel(osc, org, d, workers=8):
+    """The oracle's ray batch call is a plain loop; ctypes releases the GIL, so chunks run on threads."""
+    from concurrent.futures import ThreadPoolExecutor
+    n = org.shape[0]
+    cuts = np.linspace(0, n, workers + 1).astype(int)
+    with ThreadPoolExecutor(workers) as ex:
+        parts = list(ex.map(lambda k: osc.intersect_rays(org[cuts[k]:cuts[k + 1]], d[cuts[k]:cuts[k + 1]]), range(workers)))
+    return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+
+
+def test_pruned_closest_hit_equals_the_unpruned_search_on_slivers_and_grazing_rays(gpu):
+    """Scene::intersect in the reference is unordered and unpruned: any leaf the ray reaches may win with whatever distance its triangle test
+    returns, however ill-conditioned (mod.rs:436-441).  The kernels visit near-first and skip subtrees whose box entry lies beyond the best hit
+    (rt_kernels.h prune_limit).  The rule is held here against the oracle's unpruned search where it is weakest: 120,000 sliver triangles
+    (edge ratios 1e-3 .. 1e-7, sizes 1 .. 1e4, at distances up to 1e4) between walls, and 1.2 million rays of which a third graze a sliver or a
+    wall almost in its plane, a third aim at sliver edges, a third are random.  ids and distances bit-equal."""
+    from oracle import binding as ob
+    import rustracer_amd as ra
+    rng = np.random.default_rng(11)
+    T = 120_000
+
+    def unit(v):
+        return v / np.linalg.norm(v, axis=1, keepdims=True)
+
+    size = 10.0 ** rng.uniform(0, 4, T)
+    ratio = 10.0 ** rng.uniform(-7, -3, T)
+    p1 = rng.uniform(-1, 1, (T, 3)) * (10.0 ** rng.uniform(0, 4, (T, 1)))
+    u = unit(rng.normal(size=(T, 3)))
+    v = unit(np.cross(u, rng.normal(size=(T, 3))))
+    e1 = u * size[:, None]
+    e2 = u * (size * rng.uniform(0.05, 0.95, T))[:, None] + v * (size * ratio)[:, None]
+    tri = np.concatenate([p1, p1 + e1, p1 + e2], axis=1)
+    # walls: 12 large triangles of a box of half side 2e4
+    Lw = 2.0e4
+    c = np.array([[sx, sy, sz] for sx in (-Lw, Lw) for sy in (-Lw, Lw) for sz in (-Lw, Lw)])
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    walls = np.array([np.concatenate([c[a], c[b], c[cc]]) for q in quads for a, b, cc in ((q[0], q[1], q[2]), (q[0], q[2], q[3]))])
+    tri = np.concatenate([walls, tri]).astype(np.float32)
+    nrm = np.tile(np.array([0, 0, 1, 0, 0, 1, 0, 0, 1], np.float32), (tri.shape[0], 1))
+    mats = np.zeros((1, 8), np.uint32)
+    mats[0, 1:4] = np.float32(0.5).view(np.uint32)
+    args = (tri, nrm, np.zeros(tri.shape[0], np.uint32), np.zeros((0, 4), np.float32), np.zeros(0, np.uint32), mats)
+    osc, gsc = ob.OracleScene.raw(*args), ra.Scene.from_arrays(*args)
+
+    N = 400_000
+    t64 = tri.astype(np.float64)
+    # (a) grazing: towards a point of a triangle (sliver or wall), along a direction almost inside its plane
+    k = rng.integers(0, tri.shape[0], N)
+    a, b, cc = t64[k, 0:3], t64[k, 3:6], t64[k, 6:9]
+    w = rng.dirichlet((1, 1, 1), N)
+    q = a * w[:, :1] + b * w[:, 1:2] + cc * w[:, 2:]
+    nn = unit(np.cross(b - a, cc - a) + 1e-300)
+    inplane = unit((b - a) * rng.normal(size=(N, 1)) + (cc - a) * rng.normal(size=(N, 1)) * 1e3 + 1e-300)
+    d_a = unit(inplane + nn * (10.0 ** rng.uniform(-7, -2, (N, 1))) * rng.choice([-1.0, 1.0], (N, 1)))
+    o_a = q - d_a * (10.0 ** rng.uniform(0, 4, (N, 1)))
+    # (b) at sliver edges and vertices from afar
+    k = rng.integers(12, tri.shape[0], N)
+    a, b, cc = t64[k, 0:3], t64[k, 3:6], t64[k, 6:9]
+    s = rng.uniform(0, 1, (N, 1))
+    q = np.where(rng.uniform(size=(N, 1)) < 0.5, a + (b - a) * s, a + (cc - a) * s)
+    o_b = rng.uniform(-1.5e4, 1.5e4, (N, 3))
+    d_b = unit(q - o_b)
+    # (c) random
+    o_c = rng.uniform(-1.5e4, 1.5e4, (N, 3))
+    d_c = unit(rng.normal(size=(N, 3)))
+    org = np.concatenate([o_a, o_b, o_c]).astype(np.float32)
+    d = np.concatenate([d_a, d_b, d_c]).astype(np.float32)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    gi, gt = gsc.intersect_rays(org, d)
+    oi, ot = _oracle_intersect_parallel(osc, org, d, workers=min(len(os.sched_getaffinity(0)), 16))
+    bad = np.flatnonzero((gi != oi) | (gt.view(np.uint32) != ot.view(np.uint32)))
+    assert bad.size == 0, "%d of %d rays differ; first: ray %d gpu (%d, %r) oracle (%d, %r)" % (bad.size, org.shape[0], bad[0], gi[bad[0]], gt[bad[0]], oi[bad[0]], ot[bad[0]])
+    assert (gi[:N] != 0xFFFFFFFF).mean() > 0.9 and len(np.unique(gi)) > 20000
+
+
+def test_native_rccl_gather_at_world_1(scenes):
+    """The multi-GPU frame path (rt_comm_init_rank + rt_gather_tiles = pack -> ncclAllGather -> unpack, include/rustracer_hip.h) executed
+    on this GPU with a one-rank communicator: RCCL initialises, the collective runs on the render stream, and the frame comes back as
+    rendered (RGBA8 and a 16-byte-per-pixel payload); a shard description that does not match the communicator is refused."""
+    import torch
+    from rustracer_amd import tiles
+    from rustracer_amd._lib import RtError, check, lib
+    osc, gsc = scenes("teapot")
+    comm = tiles.Comm(1, 0, lambda ident: ident)
+    try:
+        op = oracle_params(width=200, height=150, spp=2, light_samples=2, bounces=2, tile=(32, 32), shard=(0, 1))
+        p = to_rt_params(op)
+        frame = torch.zeros((150, 200, 4), dtype=torch.uint8, device="cuda:0")
+        stream = torch.cuda.current_stream().cuda_stream
+        for _ in range(2):                                   # the second frame reuses the staging buffers
+            check(lib().rt_render_device(gsc.handle, C.byref(p), frame.data_ptr(), stream))
+            comm.gather(p, frame.data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(frame.cpu().numpy(), osc.render(op)["rgba"])
+        wide = torch.arange(150 * 200 * 4, dtype=torch.int32, device="cuda:0").reshape(150, 200, 4)
+        keep = wide.clone()
+        comm.gather(p, wide.data_ptr(), stream, bytes_per_pixel=16)
+        torch.cuda.synchronize()
+        assert torch.equal(wide, keep)
+        q = p.copy()
+        q.shard_index, q.shard_count = 1, 2
+        with pytest.raises(RtError):
+            comm.gather(q, frame.data_ptr(), stream)
+        # the host-buffer form the C++ Raytracer uses
+        rgba = np.zeros((150, 200, 4), np.uint8)
+        check(lib().rt_render_comm(gsc.handle, C.byref(p), comm._h, rgba.ctypes.data_as(C.c_void_p), None, None))
+        assert np.array_equal(rgba, osc.render(op)["rgba"])
+    finally:
+        comm.destroy()

@@ -89,6 +89,22 @@ def test_image_mode_matches_oracle(gpu, teapot_obj, tmp_path, scene, args, okw):
 
 
 @pytest.mark.gpu
+def test_image_mode_as_one_rank_of_a_multi_gpu_job(gpu, teapot_obj, tmp_path):
+    """One process per GPU (WORLD_SIZE / RANK / RT_COMM_ID_FILE): the binary makes the RCCL communicator from the id file, renders its
+    shard, gathers over RCCL (rt_render_comm) and rank 0 writes the PNG.  Run here as a job of one rank: same image as without."""
+    from oracle import binding as ob
+    env = dict(os.environ, SCENE="teapot", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", RT_COMM_ID_FILE=str(tmp_path / "rccl.id"))
+    r = subprocess.run([EXE, "-i", "--obj-dir", os.path.dirname(teapot_obj), "-w", "70", "-h", "50", "-s", "2", "-l", "2", "-b", "3"], cwd=str(tmp_path), env=env,
+                       capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr
+    m = re.search(r"Saving with filename (\./dump/\d+\.png)", r.stdout)
+    assert m and os.path.getsize(tmp_path / "rccl.id") == 128
+    img = read_png_rgb8(str(tmp_path / m.group(1)))
+    ref = ob.OracleScene.named("teapot", teapot_obj).render(ob.make_params(width=70, height=50, spp=2, light_samples=2, bounces=3))["rgba"]
+    assert np.array_equal(img, ref[:, :, :3])
+
+
+@pytest.mark.gpu
 def test_debug_flag_prints_centre_pixel(gpu, tmp_path):
     r = subprocess.run([EXE, "-i", "-d", "-w", "33", "-h", "33", "-s", "1", "-l", "1", "-b", "1"], cwd=str(tmp_path), env=dict(os.environ, SCENE="specular"),
                        capture_output=True, text=True, timeout=120)

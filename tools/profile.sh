@@ -6,6 +6,7 @@ TAG=$1; shift
 OUT=gpurun_out/prof_$TAG
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/$OUT
+python3 -c "import sys; sys.path.insert(0, '$R'); from rustracer_amd._lib import kernel_source_hash as h; print(h())" > $R/$OUT/source_hash.txt
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 1 --warmup 1 --cpu-seconds 0 --stats-spp 0 $@"
 PASSES=${PASSES:-"trace sq1 sq2 tcc fetch write tcp"}

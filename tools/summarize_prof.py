@@ -143,7 +143,9 @@ def write_pmc_json(agg, calls, src, path, workload):
     j = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of tools/profile.sh, %s" % os.path.basename(src.rstrip("/")),
          "correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950 counts 128-B requests as 64 B) + WRITE_SIZE KiB x 1024, averaged over the kernel's dispatches",
          "valu": "valu_issue_busy = 4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs); valu_active_lanes = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)",
-         "workload": workload, "kernels": kernels}
+         "workload": workload, "kernels": kernels,
+         "kernel_source_hash": (open(os.path.join(src, "source_hash.txt")).read().strip() if os.path.exists(os.path.join(src, "source_hash.txt")) else None),
+         "git_commit": os.popen("git -C %s rev-parse --short HEAD 2>/dev/null" % os.path.dirname(os.path.abspath(__file__))).read().strip() or None}
     open(path, "w").write(json.dumps(j, indent=1) + "\n")
 
 
