@@ -72,7 +72,7 @@ def main():
     # RT_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share devices, where RCCL refuses to
     # start; the tiles then travel through the host; not a measurement).
     backend = os.environ.get("RT_BENCH_BACKEND", "rccl")
-    dev_index = local_rank if backend == "rccl" else local_rank % max(torch.cuda.device_count(), 1)
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)   # one rank per GPU; on a box with fewer GPUs than ranks (a rehearsal) ranks share devices
     torch.cuda.set_device(dev_index)
     check(lib().rt_init(dev_index))
     dev = torch.device("cuda", dev_index)

@@ -114,7 +114,10 @@ int rt_scene_wide_bvh(const rt_scene* scene, uint32_t* node_words, float* prim_r
 /* do_render / debug_render (src/raytracer.rs:167, 353) for the pixels of one shard.
  * rgba: width*height*4 bytes, row-major, top row first, alpha 255 (SharedPixelBuffer,
  * src/raytracer.rs:22-51); only owned pixels are written.
- * rt_render: rgba is host memory; blocks; progress (0..100, src/raytracer.rs:79) and interrupt may be NULL.  *interrupt is
+ * rt_render: rgba is host memory; blocks; progress (0..100, src/raytracer.rs:79) and interrupt may be NULL.  With a progress word the
+ * host buffer is refreshed after every pass (a chunk of pixels x a chunk of samples): finished pixels appear chunk by chunk as the
+ * reference's columns do (src/raytracer.rs:203-214), and a pixel whose samples are spread over several passes shows the mean of the samples
+ * done so far (= the reference's image at that many spp), so a canvas polling the buffer (src/canvas.rs:179) sees the frame refine.  *interrupt is
  * polled between passes and, inside a pass, between bounce levels (the reference polls per pixel, src/raytracer.rs:184-204):
  * a render stops within one bounce level of one pass of raising it.
  * rt_render_device: rgba is device memory; work is enqueued on `stream` (hipStream_t, may be NULL)

@@ -488,8 +488,10 @@ int ensure_jump(rt_scene* s, uint32_t nlL, hipStream_t stream) {
     return RT_OK;
 }
 
+// host_rgba (optional): the caller's host frame; with a progress word it receives the device frame after every pass, so that whoever polls
+// the buffer while the render runs (the canvas, src/canvas.rs:179) sees it fill and refine as the reference's does (raytracer.rs:203-214).
 int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, hipStream_t stream, volatile uint32_t* progress,
-                const volatile uint32_t* interrupt) {
+                const volatile uint32_t* interrupt, uint8_t* host_rgba = nullptr) {
     int rc;
     if ((rc = validate_params(params))) return rc;
     if (!rgba_dev) return fail(RT_ERR_INVALID, "rgba is NULL");
@@ -592,6 +594,7 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
     pc.lray = s->w_lray.p; pc.blist = s->w_blist.p; pc.tmask = s->w_tmask.p; pc.persist = persist ? 1u : 0u;
     pc.stackA = s->w_stackA.p; pc.stackB = s->w_stackB.p; pc.radiance = s->w_radiance.p; pc.accum = s->w_accum.p;
     pc.jump = s->w_jump.p; pc.stats = s->w_stats.p; pc.rgba = rgba_dev;
+    pc.preview = (progress && host_rgba) ? 1u : 0u;
 
     const uint64_t n_pix_chunks = (sh.n_own_pix + npix_chunk - 1) / npix_chunk;
     const uint64_t n_s_chunks = (P.spp + spc - 1) / spc;
@@ -667,6 +670,8 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
             ++done;
             if (progress || interrupt) {
                 HIP_TRY(hipStreamSynchronize(stream));
+                if (pc.preview && done < total_passes)
+                    HIP_TRY(hipMemcpy(host_rgba, rgba_dev, (size_t)P.width * P.height * 4, hipMemcpyDeviceToHost));
                 if (progress) *progress = (uint32_t)((float)done / (float)total_passes * 100.0f);   // raytracer.rs:191, 213
             }
         }
@@ -823,7 +828,7 @@ int rt_render_comm(rt_scene* s, const rt_render_params* params, rt_comm* comm, u
     const size_t bytes = (size_t)params->width * params->height * 4;
     if ((rc = s->w_frame.ensure(bytes))) return rc;
     HIP_TRY(hipMemcpy(s->w_frame.p, rgba, bytes, hipMemcpyHostToDevice));   // pixels of other shards / of an interrupted render stay as the caller has them
-    rc = render_impl(s, params, s->w_frame.p, nullptr, progress, interrupt);
+    rc = render_impl(s, params, s->w_frame.p, nullptr, progress, interrupt, rgba);
     // every rank takes part in the collective, interrupted or not: a rank that skipped it would leave the others waiting
     if (comm && (rc == RT_OK || rc == RT_ERR_INTERRUPTED)) {
         const int rg = rt_gather_tiles(comm, params, s->w_frame.p, 4, nullptr);

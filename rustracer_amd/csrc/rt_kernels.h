@@ -110,6 +110,7 @@ struct PassCtx {
     const ulonglong2* jump;          // LCG jump-ahead (mul, add) by 2*j draws, j in [0, nlL]
     unsigned long long* stats;       // device counters, see ST_*
     uint8_t* rgba;                   // full frame
+    uint32_t preview;                // k_resolve also writes the running mean after every chunk of samples but the last
 };
 
 // traversal work is counted per ray class: [ST_C_*] closest-hit rays, [ST_S_*] shadow (any-hit) rays
@@ -1373,12 +1374,15 @@ __global__ void __launch_bounds__(RT_BLOCK) k_resolve(PassCtx pc) {
             const float4 r = pc.radiance[(size_t)pl * pc.spc + s];
             a.x += r.x; a.y += r.y; a.z += r.z;
         }
-        if (pc.s0 + pc.spc >= P.spp) {
-            const float inv = 1.0f / (float)P.spp;
+        const bool last = pc.s0 + pc.spc >= P.spp;
+        if (!last) pc.accum[pc.pix0 + pl] = a;
+        if (last || pc.preview) {
+            // the pixel after its last sample (raytracer.rs:238-240); with `preview`, also after every earlier chunk of samples: the mean of the
+            // samples so far, i.e. the image the reference would give at that many spp, so that a canvas polling the buffer (canvas.rs:179) sees
+            // the frame refine
+            const float inv = 1.0f / (float)(last ? P.spp : pc.s0 + pc.spc);
             const uint32_t r8 = to_color(a.x * inv), g8 = to_color(a.y * inv), b8 = to_color(a.z * inv);
             reinterpret_cast<uint32_t*>(pc.rgba)[(size_t)y * P.width + x] = r8 | (g8 << 8) | (b8 << 16) | 0xFF000000u;
-        } else {
-            pc.accum[pc.pix0 + pl] = a;
         }
     }
 }

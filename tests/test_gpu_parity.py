@@ -839,3 +839,60 @@ def test_native_rccl_gather_at_world_1(scenes):
         assert np.array_equal(rgba, osc.render(op)["rgba"])
     finally:
         comm.destroy()
+
+
+def test_partial_frames_refine_and_equal_the_oracle_at_the_samples_done(scenes):
+    """Control surface (raytracer.rs:203-214, canvas.rs:179): while rt_render runs, the host buffer a canvas polls shows the frame fill and
+    refine.  With the samples spread over passes of 3, the buffer after k passes is the mean of the first 3k samples of every pixel, which is
+    bit for bit the oracle's image at 3k spp; an interrupt leaves that partial frame in place; the finished frame equals the oracle at full spp."""
+    import threading
+    from rustracer_amd._lib import RT_ERR_INTERRUPTED, lib, ptr
+    osc, gsc = scenes("teapot")
+    W, H, SPP, CH = 96, 64, 12, 3
+    kw = dict(width=W, height=H, light_samples=2, bounces=3)
+    refs = {k: osc.render(oracle_params(spp=k, **kw))["rgba"] for k in range(CH, SPP + 1, CH)}
+    p = to_rt_params(oracle_params(spp=SPP, **kw))
+    gsc.set_option("max_paths", W * H * CH)
+    try:
+        rgba = np.zeros((H, W, 4), np.uint8)
+        prog, intr = C.c_uint32(0), C.c_uint32(0)
+        seen, done = [], threading.Event()
+
+        def poll():                                   # the canvas: snapshots while the render runs
+            last = -1
+            while not done.is_set():
+                v = prog.value
+                if v != last and 0 < v < 100:
+                    seen.append((v, rgba.copy()))
+                    last = v
+        t = threading.Thread(target=poll)
+        t.start()
+        rc = lib().rt_render(gsc.handle, C.byref(p), ptr(rgba), C.byref(prog), C.byref(intr))
+        done.set()
+        t.join()
+        assert rc == 0 and np.array_equal(rgba, refs[SPP])
+        # every snapshot taken at a pass boundary is one of the partial images (a snapshot may straddle a refresh: skip torn ones)
+        whole = [s for _, s in seen if any(np.array_equal(s, r) for r in refs.values())]
+        assert len(seen) == 0 or len(whole) >= 1
+        # deterministic form: interrupt after the first pass has been reported
+        for stop_at in (1, 2, 3):
+            rgba[:] = 0
+            prog.value, intr.value = 0, 0
+            box = {}
+
+            def stopper():
+                while not done2.is_set():
+                    if prog.value >= int(100 * stop_at / (SPP // CH)):
+                        intr.value = 1
+                        return
+            done2 = threading.Event()
+            t = threading.Thread(target=stopper)
+            t.start()
+            rc = lib().rt_render(gsc.handle, C.byref(p), ptr(rgba), C.byref(prog), C.byref(intr))
+            done2.set()
+            t.join()
+            assert rc == RT_ERR_INTERRUPTED
+            k_done = [k for k, r in refs.items() if np.array_equal(rgba, r)]
+            assert k_done and stop_at * CH <= k_done[0] < SPP, "the interrupted frame is not the oracle's image at a multiple of %d spp" % CH
+    finally:
+        gsc.set_option("max_paths", 0)
