@@ -99,6 +99,15 @@ int rt_scene_create(const float* tri_pos, const float* tri_nrm, const uint32_t* 
                     const rt_material* mats, uint32_t n_mat, rt_scene** out);
 void rt_scene_destroy(rt_scene* scene);
 int rt_scene_info_get(const rt_scene* scene, rt_scene_info* out);
+/* Where scenes are built.  "device_build" 0/1 (default 1): once rt_init has chosen a GPU, the two trees of a scene with at least
+ * "device_build_min" (default 4096) objects are built there (level-synchronous SAH build + 8-wide collapse, the host builders' trees word
+ * for word), so that Raytracer::set_scene (src/raytracer.rs:514-518) does not wait for a host build; inputs the device builder declines
+ * (a NaN, infinity or negative zero among the coordinates) and smaller scenes are built on the host.  Applies to scenes created afterwards. */
+int rt_set_global_option(const char* name, uint64_t value);
+/* Build report of a scene: ms4 = wall milliseconds of the binary tree / the 8-wide tree build, then the part of each between HIP events
+ * (uploads, kernels, downloads; 0 when built on the host), on_device2 = 1 where the GPU built it, note = why it did not when it was asked
+ * to (any pointer may be NULL). */
+int rt_scene_build_info(const rt_scene* scene, double* ms4, uint32_t* on_device2, char* note, uint32_t note_capacity);
 /* Light object indices (Scene::light_indexes, src/scene/mod.rs:495). */
 int rt_scene_lights(const rt_scene* scene, uint32_t* out, uint32_t capacity);
 /* Host copy of the flattened BVH for inspection: per inner node 16 words

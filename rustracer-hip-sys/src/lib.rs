@@ -120,6 +120,8 @@ extern "C" {
     pub fn rt_scene_create(tri_pos: *const f32, tri_nrm: *const f32, tri_mat: *const u32, n_tri: u32, sph: *const f32, sph_mat: *const u32, n_sph: u32, mats: *const rt_material, n_mat: u32, out: *mut *mut rt_scene) -> c_int;
     pub fn rt_scene_destroy(scene: *mut rt_scene);
     pub fn rt_scene_info_get(scene: *const rt_scene, out: *mut rt_scene_info) -> c_int;
+    pub fn rt_set_global_option(name: *const c_char, value: u64) -> c_int;
+    pub fn rt_scene_build_info(scene: *const rt_scene, ms4: *mut f64, on_device2: *mut u32, note: *mut c_char, note_capacity: u32) -> c_int;
     pub fn rt_scene_lights(scene: *const rt_scene, out: *mut u32, capacity: u32) -> c_int;
     pub fn rt_scene_bvh(scene: *const rt_scene, node_words: *mut u32, rank: *mut u32) -> c_int;
     pub fn rt_scene_wide_bvh(scene: *const rt_scene, node_words: *mut u32, prim_records: *mut f32) -> c_int;

@@ -63,7 +63,7 @@ class Counters(C.Structure):
 
 # every symbol include/rustracer_hip.h declares
 EXPORTS = [
-    "rt_last_error", "rt_init", "rt_scene_create", "rt_scene_destroy", "rt_scene_info_get", "rt_scene_lights", "rt_scene_bvh", "rt_scene_wide_bvh",
+    "rt_last_error", "rt_init", "rt_scene_create", "rt_scene_destroy", "rt_scene_info_get", "rt_set_global_option", "rt_scene_build_info", "rt_scene_lights", "rt_scene_bvh", "rt_scene_wide_bvh",
     "rt_render", "rt_render_device", "rt_cast_primary", "rt_cast_primary_device", "rt_cast_primary_noalloc", "rt_intersect_rays", "rt_occluded_rays",
     "rt_get_counters", "rt_set_option", "rt_tiles_per_shard", "rt_tiles_pack", "rt_tiles_unpack", "rt_comm_unique_id", "rt_comm_init_rank", "rt_comm_destroy", "rt_gather_tiles", "rt_render_comm", "rt_screen_params",
     "rt_scene_new_named", "rt_scene_new_dragon_mesh", "rt_scene_export", "rt_make_dragon_standin", "rt_debug_math", "rt_debug_rng", "rt_debug_exact",
@@ -94,6 +94,8 @@ def lib():
     L.rt_scene_destroy.argtypes = [vp]
     L.rt_scene_destroy.restype = None
     L.rt_scene_info_get.argtypes = [vp, C.POINTER(SceneInfo)]
+    L.rt_set_global_option.argtypes = [C.c_char_p, u64]
+    L.rt_scene_build_info.argtypes = [vp, vp, vp, C.c_char_p, u32]
     L.rt_scene_lights.argtypes = [vp, vp, u32]
     L.rt_scene_bvh.argtypes = [vp, vp, vp]
     L.rt_scene_wide_bvh.argtypes = [vp, vp, vp]

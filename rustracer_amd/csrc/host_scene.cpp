@@ -650,33 +650,14 @@ class WideBuilder {
         memset(q, 0, 48);
         uint32_t meta = 0;
         for (int a = 0; a < 3; ++a) {
-            typedef long double real;   // 64-bit mantissa: p + q * step below is exact for every scene the range checks admit
-            const real p = (real)nb.mn[a];
-            const real ext = (real)nb.mx[a] - p;
-            if (!(ext >= 0.0L) || !(ext < 1e300L)) return false;
-            int e = WIDE_EXP_MIN;
-            if (ext > 0.0L) {
-                int ex;
-                frexpl(ext / 253.0L, &ex);   // ext / 253 < 2^ex: at most 253 steps, leaving room for the safety step below
-                e = ex;
-            }
-            if (e < WIDE_EXP_MIN) e = WIDE_EXP_MIN;
-            if (e > WIDE_EXP_MAX) return false;
-            const real step = ldexpl(1.0L, e);
-            for (size_t k = 0; k < ch.size(); ++k) {
-                // grid plane <= exact minimum and >= exact maximum in real arithmetic, with a millionth of a step to spare
-                const real mn = (real)ch[k].box.mn[a], mx = (real)ch[k].box.mx[a];
-                real ql = floorl((mn - p) / step);
-                while (ql > 0.0L && p + ql * step > mn) ql -= 1.0L;
-                if (ql > 0.0L && (mn - (p + ql * step)) < step * 1e-6L) ql -= 1.0L;
-                real qh = ceill((mx - p) / step);
-                while (p + qh * step < mx) qh += 1.0L;
-                if (((p + qh * step) - mx) < step * 1e-6L) qh += 1.0L;
-                if (ql < 0.0L) ql = 0.0L;
-                if (qh > 255.0L || !(p + ql * step <= mn) || !(p + qh * step >= mx)) return false;
-                q[8 * a + k] = (uint8_t)ql;
-                q[24 + 8 * a + k] = (uint8_t)qh;
-            }
+            // 64-bit mantissa: nothing below rounds for scenes the range checks admit
+            float cmn[8], cmx[8];
+            for (size_t k = 0; k < ch.size(); ++k) { cmn[k] = ch[k].box.mn[a]; cmx[k] = ch[k].box.mx[a]; }
+            unsigned char ql[8], qh[8];
+            int e = 0;
+            bool inexact = false;
+            if (!wide_axis_planes<long double>(nb.mn[a], nb.mx[a], (int)ch.size(), cmn, cmx, 1, ql, qh, &e, &inexact)) return false;
+            for (size_t k = 0; k < ch.size(); ++k) { q[8 * a + k] = ql[k]; q[24 + 8 * a + k] = qh[k]; }
             for (size_t k = ch.size(); k < 8; ++k) { q[8 * a + k] = 255; q[24 + 8 * a + k] = 0; }
             meta |= (uint32_t)(e + WIDE_EXP_BIAS) << (8 * a);
         }

@@ -57,7 +57,68 @@ struct WideBVH {
     uint32_t n_prims() const { return (uint32_t)(prims.size() / 12); }
 };
 const int WIDE_EXP_BIAS = 128, WIDE_EXP_MIN = -64, WIDE_EXP_MAX = 60;
+#define WIDE_EXP_MIN_ (-64)
+#define WIDE_EXP_MAX_ 60
 const float WIDE_COORD_MAX = 1.152921504606846976e18f;   // 2^60: larger scene or ray-origin coordinates take the binary traversal
+
+// Quantised planes of one axis of an 8-wide node (shared by the host builder, in long double, and the device builder, in double with a
+// check that nothing was rounded): the grid origin is the node box minimum p, the step 2^e is the smallest power of two with
+// extent / 253 < 2^e (at most 253 steps, leaving room for the safety step), and every child plane moves outward to a grid plane that is
+// <= the exact minimum (>= the exact maximum) in real arithmetic with 2^-20 of a step to spare.  Returns false when the node is outside
+// the quantiser's range.  *inexact is set when an operation of `real` had to round (never in long double for scenes the range checks
+// admit and coordinates that differ by less than 2^40 in magnitude).
+#if defined(__HIP__)
+#define RT_QHD __host__ __device__ inline
+#else
+#define RT_QHD inline
+#endif
+template <class real>
+RT_QHD real q_sub(real a, real b, bool* inexact) {   // a - b, noting whether it was exact (TwoSum)
+    const real s = a - b;
+    const real bp = s - a;
+    const real ap = s - bp;
+    const real err = (a - ap) + (-b - bp);
+    if (err != (real)0) *inexact = true;
+    return s;
+}
+template <class real>
+RT_QHD bool wide_axis_planes(float nb_mn, float nb_mx, int n_ch, const float* ch_mn, const float* ch_mx, int stride, unsigned char* qlo, unsigned char* qhi, int* e_out,
+                             bool* inexact) {
+    const real p = (real)nb_mn;
+    const real ext = q_sub<real>((real)nb_mx, p, inexact);
+    if (!(ext >= (real)0) || !(ext < (real)1e300)) return false;
+    int e = WIDE_EXP_MIN_;
+    if (ext > (real)0) {
+        // ext = m 2^k with m in [1/2, 1): ext / 253 < 2^e first holds at e = k - 8 when m < 253/256, at e = k - 7 otherwise (exact comparisons)
+        int k = 0;
+        real m = ext;
+        while (m >= (real)1) { m = m * (real)0.5; ++k; }
+        while (m < (real)0.5) { m = m * (real)2; --k; }
+        e = k - 8 + (m >= (real)(253.0 / 256.0) ? 1 : 0);
+    }
+    if (e < WIDE_EXP_MIN_) e = WIDE_EXP_MIN_;
+    if (e > WIDE_EXP_MAX_) return false;
+    real step = (real)1;
+    for (int i = 0; i < (e < 0 ? -e : e); ++i) step = e < 0 ? step * (real)0.5 : step * (real)2;
+    const real spare = step * (real)(1.0 / 1048576.0);
+    for (int c = 0; c < n_ch; ++c) {
+        const real dmn = q_sub<real>((real)ch_mn[c * stride], p, inexact), dmx = q_sub<real>((real)ch_mx[c * stride], p, inexact);
+        real ql = dmn / step;   // exact: a power of two
+        ql = ql - (ql - (real)(long long)ql < (real)0 ? (real)1 : (real)0);
+        ql = (real)(long long)ql;                                   // floor for |ql| < 2^62
+        if (ql > (real)255) return false;
+        if (ql > (real)0 && dmn - ql * step < spare) ql -= (real)1;
+        real qh = dmx / step;
+        { const real t = (real)(long long)qh; qh = t < qh ? t + (real)1 : t; }   // ceil
+        if (qh * step - dmx < spare) qh += (real)1;
+        if (ql < (real)0) ql = (real)0;
+        if (qh > (real)255 || !(ql * step <= dmn) || !(qh * step >= dmx)) return false;
+        qlo[c] = (unsigned char)ql;
+        qhi[c] = (unsigned char)qh;
+    }
+    *e_out = e;
+    return true;
+}
 
 bool scene_is_black(const float* rgb);   // Spectrum::is_black, src/common.rs:40-43
 void build_bvh(const HostScene& sc, FlatBVH* out);

@@ -10,7 +10,10 @@
 
 #include "../../include/rustracer_hip.h"
 #include "host_scene.h"
+#include "rt_build.h"
 #include "rt_kernels.h"
+
+#include <chrono>
 
 using namespace rt;
 
@@ -21,6 +24,9 @@ thread_local std::string g_error;
 // threads of their own (Raytracer::render(false) spawns one, src/raytracer.rs:527), so every entry point that touches HIP
 // selects the device again: the scene's (recorded at creation) or, for calls without a scene, the process's.
 int g_device = 0;
+bool g_inited = false;          // rt_init has chosen a GPU: scenes may be built there
+uint32_t g_device_build = 1;    // rt_set_global_option("device_build"): build the trees of scenes with >= g_device_build_min objects on the GPU
+uint32_t g_device_build_min = 4096;
 
 int fail(int code, const std::string& msg) {
     g_error = msg;
@@ -98,6 +104,10 @@ struct rt_scene {
     std::vector<uint32_t> lights;
     bool has_triangle_light = false;
     bool uploaded = false;
+    double build_dev_ms[2] = {0.0, 0.0};         // of which between HIP events (uploads, kernels, downloads; not the allocations)
+    double build_ms[2] = {0.0, 0.0};             // wall time of the binary / 8-wide tree build
+    uint32_t build_on_device[2] = {0u, 0u};      // ... and whether the GPU built it
+    std::string build_note;                      // why the GPU did not (when it was asked to)
     uint32_t ovf_rows = 0;                       // traversal-stack rows beyond RT_STACK_LDS that the trees of this scene can need
     const unsigned long long* stats_src = nullptr;   // where the counters of the last call live (w_stats, or the no-alloc scratch)
 
@@ -147,8 +157,26 @@ uint32_t grid_for(const rt_scene* s, uint64_t n) {
 void prepare_host(rt_scene* s) {
     const HostScene& h = s->host;
     const uint32_t T = h.n_tri(), S = h.n_sph();
-    build_bvh(h, &s->bvh);
-    build_wide_bvh(h, s->bvh, &s->wide);
+    // Scene::new's BVH::build (src/scene/mod.rs:99) and the occlusion tree: on the GPU when one has been chosen and the scene is large
+    // enough to pay for the launches (same trees either way: rt_build.hip), on the host otherwise.
+    const bool try_device = g_inited && g_device_build && T + S >= g_device_build_min && hipSetDevice(g_device) == hipSuccess;
+    typedef std::chrono::steady_clock clk;
+    s->build_note.clear();
+    clk::time_point t0 = clk::now();
+    std::string why;
+    s->build_on_device[0] = try_device && device_build_bvh(h, &s->bvh, &s->build_dev_ms[0], &why) ? 1u : 0u;
+    if (!s->build_on_device[0]) {
+        if (try_device) { s->build_note = "binary tree: " + why; (void)hipGetLastError(); }
+        build_bvh(h, &s->bvh);
+    }
+    clk::time_point t1 = clk::now();
+    s->build_on_device[1] = try_device && device_build_wide_bvh(h, s->bvh, &s->wide, &s->build_dev_ms[1], &why) ? 1u : 0u;
+    if (!s->build_on_device[1]) {
+        if (try_device) { s->build_note += (s->build_note.empty() ? "" : "; ") + std::string("8-wide tree: ") + why; (void)hipGetLastError(); }
+        build_wide_bvh(h, s->bvh, &s->wide);
+    }
+    s->build_ms[0] = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    s->build_ms[1] = std::chrono::duration<double, std::milli>(clk::now() - t1).count();
     s->lights.clear();
     s->has_triangle_light = false;
     for (uint32_t i = 0; i < T; ++i)
@@ -739,6 +767,7 @@ int rt_init(int device) {
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipFree(nullptr));
     g_device = device;
+    g_inited = true;
     void* scratch_ptr = nullptr;
     return scratch_for(device, &scratch_ptr);   // the no-alloc entry point's scratch: its device address is looked up here, once per GPU
 }
@@ -790,6 +819,23 @@ int rt_scene_info_get(const rt_scene* s, rt_scene_info* out) {
     out->n_lights = (uint32_t)s->lights.size();
     out->n_inner_nodes = s->bvh.n_inner(); out->bvh_depth = s->bvh.depth; out->device_bytes = s->device_bytes;
     out->n_wide_nodes = s->wide.n_nodes(); out->n_wide_prims = s->wide.n_prims(); out->wide_depth = s->wide.depth; out->reserved = 0;
+    return RT_OK;
+}
+
+int rt_set_global_option(const char* name, uint64_t value) {
+    if (!name) return fail(RT_ERR_INVALID, "NULL argument");
+    const std::string n(name);
+    if (n == "device_build") g_device_build = value ? 1u : 0u;
+    else if (n == "device_build_min") g_device_build_min = (uint32_t)value;
+    else return fail(RT_ERR_INVALID, "unknown option '" + n + "'");
+    return RT_OK;
+}
+
+int rt_scene_build_info(const rt_scene* s, double* ms4, uint32_t* on_device2, char* note, uint32_t note_capacity) {
+    if (!s) return fail(RT_ERR_INVALID, "NULL scene");
+    if (ms4) { ms4[0] = s->build_ms[0]; ms4[1] = s->build_ms[1]; ms4[2] = s->build_dev_ms[0]; ms4[3] = s->build_dev_ms[1]; }
+    if (on_device2) { on_device2[0] = s->build_on_device[0]; on_device2[1] = s->build_on_device[1]; }
+    if (note && note_capacity) { strncpy(note, s->build_note.c_str(), note_capacity - 1); note[note_capacity - 1] = 0; }
     return RT_OK;
 }
 

@@ -134,6 +134,14 @@ class Scene:
             raise RuntimeError("scene was destroyed")
         return self._h
 
+    def build_info(self):
+        """(ms of the binary / 8-wide tree build, which of them the GPU built, why not)."""
+        ms = (C.c_double * 4)()
+        dev = (C.c_uint32 * 2)()
+        note = C.create_string_buffer(512)
+        check(lib().rt_scene_build_info(self.handle, ms, dev, note, 512))
+        return {"binary_ms": ms[0], "wide_ms": ms[1], "binary_device_ms": ms[2], "wide_device_ms": ms[3], "binary_on_device": bool(dev[0]), "wide_on_device": bool(dev[1]), "note": note.value.decode()}
+
     def light_indexes(self):
         out = np.zeros(self.info.n_lights, np.uint32)
         check(lib().rt_scene_lights(self.handle, ptr(out), out.shape[0]))

@@ -896,3 +896,49 @@ def test_partial_frames_refine_and_equal_the_oracle_at_the_samples_done(scenes):
             assert k_done and stop_at * CH <= k_done[0] < SPP, "the interrupted frame is not the oracle's image at a multiple of %d spp" % CH
     finally:
         gsc.set_option("max_paths", 0)
+
+
+@pytest.mark.parametrize("name", ["teapot", "specular", "dragon_small", "dragon_full", "chain"])
+def test_device_built_trees_equal_the_host_built(gpu, teapot_obj, name):
+    """SURVEY.md 8f-3: BVH::build (mod.rs:99) and the 8-wide occlusion tree built on the GPU are the host builders' trees word for word
+    (node words, pre-order numbering, ranks; wide nodes and primitive records), from 13 objects to the 871,210 of the full stand-in."""
+    import rustracer_amd as ra
+    from rustracer_amd._lib import check, lib
+
+    def make():
+        if name == "dragon_small":
+            return ra.Scene.from_dragon_mesh(*ra.dragon_standin_mesh(500, 100))
+        if name == "dragon_full":
+            return ra.Scene.from_dragon_mesh(*ra.dragon_standin_mesh(*ra.DRAGON_STANDIN_FULL))
+        if name == "chain":                                   # a 31-deep chain of spheres: halved splits, leaves at every level
+            n = 74
+            z = -(1e-4 * 2.0 ** np.arange(n))
+            sph = np.stack([np.zeros(n) + 0.25, np.zeros(n) + 0.5, z, 0.02 * np.abs(z)], axis=1).astype(np.float32)
+            mats = np.zeros((1, 8), np.uint32)
+            return ra.Scene.from_arrays(np.zeros((0, 9)), np.zeros((0, 9)), [], sph, np.zeros(n, np.uint32), mats)
+        return ra.Scene._named(name, teapot_obj)
+
+    L = lib()
+    try:
+        check(L.rt_set_global_option(b"device_build_min", 2))
+        check(L.rt_set_global_option(b"device_build", 0))
+        host = make()
+        check(L.rt_set_global_option(b"device_build", 1))
+        dev = make()
+    finally:
+        check(L.rt_set_global_option(b"device_build", 1))
+        check(L.rt_set_global_option(b"device_build_min", 4096))
+    hi, di = host.build_info(), dev.build_info()
+    assert not hi["binary_on_device"] and di["binary_on_device"], di
+    print("\n%s: %d objects; binary tree host %.1f ms, GPU %.1f ms (%.1f between events); 8-wide tree host %.1f ms, %s %.1f ms (%.1f between events)"
+          % (name, dev.info.n_tri + dev.info.n_sph, hi["binary_ms"], di["binary_ms"], di["binary_device_ms"], hi["wide_ms"],
+             "GPU" if di["wide_on_device"] else "host", di["wide_ms"], di["wide_device_ms"]))
+    hw, hr = host.bvh()
+    dw, dr = dev.bvh()
+    assert host.info.bvh_depth == dev.info.bvh_depth and host.info.n_inner_nodes == dev.info.n_inner_nodes
+    assert np.array_equal(hr, dr)
+    assert np.array_equal(hw, dw), "%d node words differ, first node %d" % (int((hw != dw).sum()), int(np.argwhere(hw != dw)[0][0]))
+    hn, hp = host.wide_bvh()
+    dn, dp = dev.wide_bvh()
+    assert host.info.wide_depth == dev.info.wide_depth
+    assert np.array_equal(hn, dn) and np.array_equal(hp.view(np.uint32), dp.view(np.uint32))
