@@ -234,6 +234,23 @@ __device__ __forceinline__ bool slab(const BoxRay& r, float mnx, float mny, floa
     return !miss && (ray_max > 0.0f);
 }
 
+// The same test with the box given relative to the ray origin (b - o, the first operation of every term above): a path vertex sends many
+// rays from one origin, so k_light subtracts once per vertex.  Same operations on the same values.
+__device__ __forceinline__ bool slab_rel(const BoxRay& r, float dnx, float dny, float dnz, float dxx, float dxy, float dxz) {
+    float ray_min = (r.sx ? dxx : dnx) * r.ix;
+    float ray_max = (r.sx ? dnx : dxx) * r.ix;
+    const float y_min = (r.sy ? dxy : dny) * r.iy;
+    const float y_max = (r.sy ? dny : dxy) * r.iy;
+    bool miss = (ray_min > y_max) || (y_min > ray_max);
+    if (y_min > ray_min) ray_min = y_min;
+    if (y_max < ray_max) ray_max = y_max;
+    const float z_min = (r.sz ? dxz : dnz) * r.iz;
+    const float z_max = (r.sz ? dnz : dxz) * r.iz;
+    miss = miss || (ray_min > z_max) || (z_min > ray_max);
+    if (z_max < ray_max) ray_max = z_max;
+    return !miss && (ray_max > 0.0f);
+}
+
 // Object::intersect, triangle arm (src/scene/objects.rs:38-57).  The edges e1 = p2 - p1, e2 = p3 - p1 are the first two operations
 // of the reference's function; hit_triangle_e takes them ready-made (the occluder cache computes them once, on the host).
 __device__ __forceinline__ bool hit_triangle_e(vec3 p1, vec3 e1, vec3 e2, vec3 o, vec3 d, float* t_out);
@@ -1027,8 +1044,11 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
         }
         // its record in the occlusion BVH: k_trace_p need not test it again for the rays that pass the test here
         const uint32_t self_rec = (self_is_tri || self_is_sph) ? sc.wrec[self_obj] : RT_W_NO_REC;
-        const float bmnx = lo3(A.x, B.x, C.x), bmny = lo3(A.y, B.y, C.y), bmnz = lo3(A.z, B.z, C.z);
-        const float bmxx = hi3(A.x, B.x, C.x), bmxy = hi3(A.y, B.y, C.y), bmxz = hi3(A.z, B.z, C.z);
+        // its own box (Bounded, objects.rs:293-316), relative to the vertex: one slab test serves the triangle and the sphere lanes of a wave
+        const float own_dnx = (self_is_sph ? A.x - A.w : lo3(A.x, B.x, C.x)) - p.x, own_dny = (self_is_sph ? A.y - A.w : lo3(A.y, B.y, C.y)) - p.y,
+                    own_dnz = (self_is_sph ? A.z - A.w : lo3(A.z, B.z, C.z)) - p.z;
+        const float own_dxx = (self_is_sph ? A.x + A.w : hi3(A.x, B.x, C.x)) - p.x, own_dxy = (self_is_sph ? A.y + A.w : hi3(A.y, B.y, C.y)) - p.y,
+                    own_dxz = (self_is_sph ? A.z + A.w : hi3(A.z, B.z, C.z)) - p.z;
         // the part of the own triangle's test that depends on the vertex only (hit_triangle_o), once for all its light samples
         const vec3 own_e1 = sub(xyz(B), xyz(A)), own_e2 = sub(xyz(C), xyz(A)), own_s = sub(p, xyz(A));
         const vec3 own_s2 = cross3(own_s, own_e1);
@@ -1045,11 +1065,13 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
           const uint32_t hg = g < RT_HOT_LIGHTS ? g : 0u;
           const bool has_hot = g < RT_HOT_LIGHTS;
           // the part of the cached triangles' test that depends on the vertex only (hit_triangle_o)
-          vec3 hot_s[RT_HOT], hot_s2[RT_HOT];
+          vec3 hot_s[RT_HOT], hot_s2[RT_HOT], hot_dn[RT_HOT], hot_dx[RT_HOT];
           float hot_tn[RT_HOT];
 #pragma unroll
           for (int h = 0; h < RT_HOT; ++h) {
               const HotRec& hr = hot.rec[hg][h];
+              hot_dn[h] = sub(mk(hr.mn[0], hr.mn[1], hr.mn[2]), p);          // its own box relative to the vertex (slab_rel)
+              hot_dx[h] = sub(mk(hr.mx[0], hr.mx[1], hr.mx[2]), p);
               hot_s[h] = sub(p, mk(hr.a[0], hr.a[1], hr.a[2]));
               hot_s2[h] = cross3(hot_s[h], mk(hr.e1[0], hr.e1[1], hr.e1[2]));
               hot_tn[h] = dot3(hot_s2[h], mk(hr.e2[0], hr.e2[1], hr.e2[2]));
@@ -1062,15 +1084,15 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
             bool blocked = false;
             const BoxRay br = make_box_ray(p, wi);
             const bool binary = !wide_ray_ok(br, p);
-            if (!binary && (self_is_tri || self_is_sph)) {
-                float t = 0.0f, tn;
+            if (!binary && (self_is_tri || self_is_sph) && slab_rel(br, own_dnx, own_dny, own_dnz, own_dxx, own_dxy, own_dxz)) {
+                float t = 0.0f;
                 bool ok;
                 if (self_is_tri) {
                     if (STATS) tst.tris++;
-                    ok = slab(br, bmnx, bmny, bmnz, bmxx, bmxy, bmxz, &tn) && hit_triangle_o(own_e1, own_e2, own_s, own_s2, own_tn, wi, &t);
+                    ok = hit_triangle_o(own_e1, own_e2, own_s, own_s2, own_tn, wi, &t);
                 } else {
                     if (STATS) tst.sphs++;
-                    ok = slab(br, A.x - A.w, A.y - A.w, A.z - A.w, A.x + A.w, A.y + A.w, A.z + A.w, &tn) && hit_sphere(A, p, wi, &t);
+                    ok = hit_sphere(A, p, wi, &t);
                 }
                 blocked = ok && t > 0.0f && t < d_s;
             }
@@ -1078,16 +1100,16 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
             for (int h = 0; h < RT_HOT; ++h) {
                 const HotRec& hr = hot.rec[hg][h];      // kernel argument: scalar loads, operands straight from SGPRs
                 if (has_hot && hr.kind != 2u && hr.rec != self_rec && !binary && !blocked) {      // (uniform but for the last three)
-                    float t = 0.0f, tn;
+                    float t = 0.0f;
                     bool ok;
                     if (hr.kind == 0u) {
                         if (STATS) tst.tris++;
                         ok = hit_triangle_o(mk(hr.e1[0], hr.e1[1], hr.e1[2]), mk(hr.e2[0], hr.e2[1], hr.e2[2]), hot_s[h], hot_s2[h], hot_tn[h], wi, &t) &&
-                             t > 0.0f && t < d_s && slab(br, hr.mn[0], hr.mn[1], hr.mn[2], hr.mx[0], hr.mx[1], hr.mx[2], &tn);
+                             t > 0.0f && t < d_s && slab_rel(br, hot_dn[h].x, hot_dn[h].y, hot_dn[h].z, hot_dx[h].x, hot_dx[h].y, hot_dx[h].z);
                     } else {
                         if (STATS) tst.sphs++;
                         ok = hit_sphere(make_float4(hr.a[0], hr.a[1], hr.a[2], hr.e1[0]), p, wi, &t) && t > 0.0f && t < d_s &&
-                             slab(br, hr.mn[0], hr.mn[1], hr.mn[2], hr.mx[0], hr.mx[1], hr.mx[2], &tn);
+                             slab_rel(br, hot_dn[h].x, hot_dn[h].y, hot_dn[h].z, hot_dx[h].x, hot_dx[h].y, hot_dx[h].z);
                     }
                     blocked = ok;
                 }
@@ -1280,6 +1302,10 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_b(DevScene sc, PassCtx pc, u
                         const vec3 le = xyz(sc.mats[2 * (sc.sph_aux[light - sc.n_tri].y & ~RT_INFO_BLOCKER) + 1]);
                         const vec3 base = mul3(le, f);
                         const float d_c = length3(sub(xyz(cr), p));
+                        // Object::sample_l's cos_a = (d_c^2 + r^2 - d_s^2) / (2 d_c r), objects.rs:109-113: the divisor and its reciprocal are the vertex's
+                        const float num0 = d_c * d_c + cr.w * cr.w, den = 2.0f * d_c * cr.w;
+                        const bool den_mid = div_range(den);
+                        const float rcp_den = rcp_mid(den);
                         vec3 color = mk(0.0f, 0.0f, 0.0f);
                         const size_t row0 = ls_slot(e & ~63u, g * L, pc.nlL);                                  // first slot of the row of sample s: + 64 s
                         const unsigned long long* mrow = pc.tmask + (size_t)(e >> 6) * pc.nlL + (size_t)g * L;  // mask of that row: + s
@@ -1303,7 +1329,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_b(DevScene sc, PassCtx pc, u
                             for (uint32_t k = 0; k < 8; ++k)
                                 if (!(w[k] & RT_LR_BLOCKED)) {
                                     const float d_s = r[k].w;
-                                    const float cos_a = div_ieee(d_c * d_c + cr.w * cr.w - d_s * d_s, 2.0f * d_c * cr.w);   // Object::sample_l, objects.rs:109-113
+                                    const float num = num0 - d_s * d_s;
+                                    const float cos_a = (den_mid && div_range(num)) ? div_mid(num, den, rcp_den) : num / den;
                                     const float pdf = 2.0f * RT_PI * (1.0f - cos_a);
                                     const float cos_theta = fabsf(dot3(xyz(r[k]), nrm));                                  // raytracer.rs:278
                                     color = add(color, scale(scale(base, cos_theta), pdf));                               // raytracer.rs:279
