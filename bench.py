@@ -243,6 +243,7 @@ def main():
         roofline = {
             "bound": "hbm", "achieved": d["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["frac_of_hbm_peak"],
             "traffic": d["traffic"], "traffic_source": pmc.get("_source"), "traffic_note": pmc.get("_note"),
+            "traffic_GBps": (round(d["traffic"] / max(d["avg_launch_ms"], 1e-9) / 1e6, 1) if d.get("traffic") else None),
             "kernel": "%s (%s)" % (dom, d["what"]), "bytes_per_unit": d["bytes_per_unit"], "unit_of_work": d["unit"],
             "units_per_launch": d["units_per_launch"], "avg_launch_ms": d["avg_launch_ms"], "launches_per_step": d["launches_per_step"],
             "limiter": {"kind": "VALU issue", "valu_issue_busy": d.get("valu_issue_busy"), "valu_active_lanes": d.get("valu_active_lanes"),
@@ -253,9 +254,11 @@ def main():
             "kernels": kernels,
             "kernel_ms_per_step": {"k_light": round(cnt["kernel_ms_light"], 2), "k_trace_p": round(cnt["kernel_ms_shadow"], 2),
                                    "k_extend": round(cnt["kernel_ms_closest"], 2), "shade+generate+resolve+k_binary": round(cnt["kernel_ms_shade"], 2)},
-            "note": "achieved = algorithmic bytes per launch / HIP-event launch time of the dominant kernel; the scene (%.0f MB) is resident in L2 / "
-                    "Infinity Cache, so `traffic` (L2<->fabric bytes per launch from the TCC counters) is served mostly by the Infinity Cache"
-                    % (scene.info.device_bytes / 1e6),
+            "note": "achieved = algorithmic bytes per launch / HIP-event launch time of the dominant kernel (the kernel with the largest share of "
+                    "the frame; k_light and k_trace_p are within a few percent of each other, see `kernels`).  The scene (%.0f MB) is resident in L2 / "
+                    "Infinity Cache: most algorithmic bytes (BVH nodes, primitive records) are served on-die, so `achieved` can exceed what HBM "
+                    "delivers; `traffic` / `traffic_GBps` are the L2<->fabric bytes per launch measured with the TCC counters.  Every kernel that "
+                    "matters is bound by VALU instruction issue (`limiter`), not by memory" % (scene.info.device_bytes / 1e6),
         }
 
     # ---- CPU baseline: the oracle (reference algorithm, unpruned traversal, recursive integrator) on a bounded sample ----
