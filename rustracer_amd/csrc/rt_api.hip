@@ -122,7 +122,7 @@ struct rt_scene {
     DevBuf<uint32_t> w_counts, w_hit_id, w_blist;
     DevBuf<float> w_hit_t;
     DevBuf<float4> w_ray_o[2], w_ray_d[2], w_vP, w_vN, w_vS, w_contrib, w_direct, w_stackA, w_stackB, w_radiance, w_accum;
-    DevBuf<float4> w_lray;
+    DevBuf<float4> w_lray, w_linv;
     DevBuf<uint64_t> w_rng;
     DevBuf<unsigned long long> w_tmask;
     DevBuf<ulonglong2> w_jump;
@@ -678,7 +678,8 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
         if (!rc) rc = s->w_vN.ensure(cap_paths);
         if (!rc) rc = s->w_vS.ensure(cap_paths);
         if (!rc) rc = s->w_rng.ensure(cap_paths);
-        if (!rc && persist) rc = s->w_lray.ensure(2 * cap_slots);
+        if (!rc && persist) rc = s->w_lray.ensure(cap_slots);
+        if (!rc && persist) rc = s->w_linv.ensure(cap_slots);
         if (!rc && persist) rc = s->w_blist.ensure(cap_slots);
         if (!rc && persist) rc = s->w_tmask.ensure(cap_slots / 64);
         if (!rc && !persist && !in_wave) rc = s->w_contrib.ensure(cap_paths * (nlL ? nlL : 1));
@@ -694,7 +695,7 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
         HIP_TRY(hipStreamSynchronize(stream));
         for (int q = 0; q < 2; ++q) { s->w_ray_o[q].release(); s->w_ray_d[q].release(); }
         s->w_hit_id.release(); s->w_hit_t.release(); s->w_vP.release(); s->w_vN.release(); s->w_vS.release(); s->w_rng.release();
-        s->w_lray.release(); s->w_blist.release(); s->w_tmask.release(); s->w_contrib.release(); s->w_direct.release();
+        s->w_lray.release(); s->w_linv.release(); s->w_blist.release(); s->w_tmask.release(); s->w_contrib.release(); s->w_direct.release();
         s->w_stackA.release(); s->w_stackB.release(); s->w_radiance.release(); s->w_accum.release();
     }
     if ((rc = ensure_jump(s, nlL, stream))) return rc;
@@ -709,7 +710,7 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
     for (int q = 0; q < 2; ++q) { pc.ray_o[q] = s->w_ray_o[q].p; pc.ray_d[q] = s->w_ray_d[q].p; }
     pc.hit_id = s->w_hit_id.p; pc.hit_t = s->w_hit_t.p;
     pc.vP = s->w_vP.p; pc.vN = s->w_vN.p; pc.rng = s->w_rng.p; pc.contrib = s->w_contrib.p; pc.direct = s->w_direct.p; pc.in_wave = in_wave ? 1u : 0u;
-    pc.lray = s->w_lray.p; pc.blist = s->w_blist.p; pc.tmask = s->w_tmask.p; pc.persist = persist ? 1u : 0u;
+    pc.lray = s->w_lray.p; pc.linv = s->w_linv.p; pc.blist = s->w_blist.p; pc.tmask = s->w_tmask.p; pc.persist = persist ? 1u : 0u;
     pc.stackA = s->w_stackA.p; pc.stackB = s->w_stackB.p; pc.radiance = s->w_radiance.p; pc.accum = s->w_accum.p;
     pc.jump = s->w_jump.p; pc.stats = s->w_stats.p; pc.rgba = rgba_dev;
     pc.preview = (progress && host_rgba) ? 1u : 0u;
@@ -897,7 +898,7 @@ void rt_scene_destroy(rt_scene* s) {
     s->w_counts.release(); s->w_hit_id.release(); s->w_blist.release(); s->w_hit_t.release();
     for (int q = 0; q < 2; ++q) { s->w_ray_o[q].release(); s->w_ray_d[q].release(); }
     s->w_vP.release(); s->w_vN.release(); s->w_vS.release(); s->w_contrib.release(); s->w_direct.release(); s->w_stackA.release(); s->w_stackB.release();
-    s->w_radiance.release(); s->w_accum.release(); s->w_tmask.release(); s->w_lray.release(); s->w_rng.release(); s->w_jump.release(); s->w_stats.release();
+    s->w_radiance.release(); s->w_accum.release(); s->w_tmask.release(); s->w_lray.release(); s->w_linv.release(); s->w_rng.release(); s->w_jump.release(); s->w_stats.release();
     s->w_frame.release(); s->w_ids.release(); s->w_ts.release(); s->w_rays.release();
     for (size_t i = 0; i < s->events.size(); ++i) { (void)hipEventDestroy(s->events[i].a); (void)hipEventDestroy(s->events[i].b); }
     delete s;

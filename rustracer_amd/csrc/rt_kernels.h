@@ -100,8 +100,9 @@ struct PassCtx {
     float4* direct;                  // per vertex: light-sample sum (in_wave)
     uint32_t in_wave;                // nlL divides 64: k_shadow sums a vertex's light samples inside the wave
     unsigned long long* tmask;       // per row (64 vertices x one light sample), k_light: the vertices whose ray is not yet settled as blocked
-    float4* lray;                    // those rays, packed at the front of their row in lane order, 2 x float4 each: (wi, distance to the light sample),
-                                     // (1/d of the box test, word: RT_LR_* | occlusion-BVH record of the object the ray starts on)
+    float4* lray;                    // those rays, packed at the front of their row in lane order: (wi, distance to the light sample; its sign bit is set
+                                     // by k_trace_p / k_binary when the ray is occluded: all k_shade_b reads of a ray)
+    float4* linv;                    // same places, for the traversal: (1/d of the box test, word: RT_LR_* | occlusion-BVH record of the object the ray starts on)
     uint32_t persist;                // light samples go through k_light + k_trace_p; k_shade_b sums the rays left unblocked in pc.lray
     float4* stackA;                  // [level][slot] (direct rgb, cos)
     float4* stackB;                  // [level][slot] (reflected rgb, pdf)
@@ -1008,7 +1009,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SHADOW_WAVES) k_shadow(DevScene s
 // are packed at the front of their row (pc.tmask[row] says which vertices they belong to; a ray's place is
 // the number of set bits below its lane), so that the kernels after k_light touch whole 64-byte sectors.
 // What the reference computes for a visible sample only (pdf, |wi.n|) is left to k_shade_b.
-#define RT_LR_BLOCKED 0x80000000u   // set by k_trace_p / k_binary: the ray is occluded
+#define RT_LR_BLOCKED 0x80000000u   // sign bit of the ray's distance in pc.lray, set by k_trace_p / k_binary: the ray is occluded (a distance is never negative)
 #define RT_LR_LANE_SHIFT 23         // bits 23..28: the ray's vertex within its tile of 64 (bits 0..22: the record of the object it starts on)
 #define RT_LR_BINARY 0x40000000u    // the ray has a non-finite or huge 1/d: k_binary settles it on the binary tree, k_trace_p drops it
 __device__ __forceinline__ size_t ls_slot(uint32_t e, uint32_t j, uint32_t nlL) {
@@ -1120,8 +1121,8 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
             const unsigned long long m = __ballot(keep);      // the whole wave is here: one row of 64 slots
             if (keep) {
                 const size_t at = row + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                pc.lray[2 * at] = make_float4(wi.x, wi.y, wi.z, d_s);
-                pc.lray[2 * at + 1] = make_float4(br.ix, br.iy, br.iz, __uint_as_float(self_rec | (__lane_id() << RT_LR_LANE_SHIFT) | (binary ? RT_LR_BINARY : 0u)));
+                pc.lray[at] = make_float4(wi.x, wi.y, wi.z, d_s);
+                pc.linv[at] = make_float4(br.ix, br.iy, br.iz, __uint_as_float(self_rec | (__lane_id() << RT_LR_LANE_SHIFT) | (binary ? RT_LR_BINARY : 0u)));
                 if (binary) pc.blist[atomicAdd(&pc.bcounts[level], 1u)] = (uint32_t)at;
             }
             if (__lane_id() == 0u) row_mask[j] = m;
@@ -1147,14 +1148,14 @@ __global__ void __launch_bounds__(RT_BLOCK) k_binary(DevScene sc, PassCtx pc, ui
         size_t at = 0;
         if (have) {
             at = pc.blist[i];
-            const float4 R4 = pc.lray[2 * at];
-            const uint32_t e = (uint32_t)(at / (64u * (size_t)pc.nlL)) * 64u + ((words[8 * at + 7] >> RT_LR_LANE_SHIFT) & 63u);
+            const float4 R4 = pc.lray[at];
+            const uint32_t e = (uint32_t)(at / (64u * (size_t)pc.nlL)) * 64u + ((__float_as_uint(pc.linv[at].w) >> RT_LR_LANE_SHIFT) & 63u);
             o = xyz(pc.vP[e]); d = xyz(R4); max_dist = R4.w;
             if (sc.self_test) self_obj = __float_as_uint(pc.vN[e].w) - 1u;
         }
         bool occ = false;
         traverse<1, STATS>(sc, have, o, d, max_dist, self_obj, st, nullptr, nullptr, &occ, &tst);
-        if (have && occ) words[8 * at + 7] |= RT_LR_BLOCKED;
+        if (have && occ) words[4 * at + 3] |= RT_LR_BLOCKED;
     }
     flush_stats<STATS>(pc.stats, tst, ST_S_INNER);
 }
@@ -1229,7 +1230,7 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
                 const uint32_t got = pub[irank], src = got & 63u;
                 slot = row_base + (got >> 8);
                 const uint32_t e = row_tile * 64u + src;
-                const float4 R4 = pc.lray[2 * (size_t)slot], I4 = pc.lray[2 * (size_t)slot + 1];
+                const float4 R4 = pc.lray[slot], I4 = pc.linv[slot];
                 const float4 P4 = pc.vP[e];
                 rec_word = __float_as_uint(I4.w);
                 o = xyz(P4); d = xyz(R4); max_dist = R4.w;
@@ -1253,7 +1254,7 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
             if (at_node) wide_node_step<STATS>(sc, br, lim, skip_rec, cur, st, &tst);
         } else {
             if (STATS) { w_steps[2]++; w_steps[3] += n_prim; }
-            if (at_prim && wide_prim_step<STATS>(sc, br, o, d, max_dist, cur, st, &tst)) words[8 * (size_t)slot + 7] = rec_word | RT_LR_BLOCKED;
+            if (at_prim && wide_prim_step<STATS>(sc, br, o, d, max_dist, cur, st, &tst)) words[4 * (size_t)slot + 3] = __float_as_uint(max_dist) | RT_LR_BLOCKED;
         }
     }
     flush_stats<STATS>(pc.stats, tst, ST_S_INNER);
@@ -1295,7 +1296,6 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_b(DevScene sc, PassCtx pc, u
                     // a blocked sample adds nothing.  pdf (objects.rs:109-115) and |wi.n| (raytracer.rs:278) are worked out here, for those only.
                     const vec3 f = __float_as_uint(m0.x) == RT_BSDF_DIFFUSE ? scale(mk(m0.y, m0.z, m0.w), 1.0f / RT_PI) : mk(0.0f, 0.0f, 0.0f);   // Object::bsdf
                     const uint32_t lane = __lane_id();
-                    const uint32_t* words = reinterpret_cast<const uint32_t*>(pc.lray);
                     for (uint32_t g = 0; g < pc.n_groups; ++g) {
                         const uint32_t light = sc.lights[g];
                         const float4 cr = sc.sph[light - sc.n_tri];
@@ -1321,8 +1321,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_b(DevScene sc, PassCtx pc, u
                                 r[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                                 if ((mk8[k] >> lane) & 1ull) {
                                     const size_t at = row0 + 64 * (size_t)(s0 + k) + (size_t)__popcll(mk8[k] & ((1ull << lane) - 1ull));
-                                    w[k] = words[8 * at + 7];
-                                    r[k] = pc.lray[2 * at];
+                                    r[k] = pc.lray[at];
+                                    w[k] = __float_as_uint(r[k].w);
                                 }
                             }
 #pragma unroll
