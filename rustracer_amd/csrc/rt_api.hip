@@ -135,7 +135,7 @@ struct rt_scene {
 
     bool opt_stats = false, opt_timing = false;
     uint64_t opt_max_paths = 1ull << 24;
-    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 16, opt_phase_bias = 4, opt_shadow_waves = 8, opt_light_waves = 4, opt_hot = 1;
+    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 16, opt_phase_bias = 4, opt_shadow_waves = 8, opt_light_waves = 4, opt_hot = 1, opt_extend_persist = 1, opt_extend_refill = 24, opt_extend_inner = 20, opt_extend_grid = 8;
     uint32_t grid_max = 2048;
 
     std::vector<EventPair> events;
@@ -518,7 +518,7 @@ int upload_scene(rt_scene* s) {
         }
     }
     d.n_wnodes = (s->wide.ok && s->opt_wide) ? s->wide.n_nodes() : 0u;
-    d.refill_min = s->opt_refill_min; d.phase_bias = s->opt_phase_bias;
+    d.refill_min = s->opt_refill_min; d.phase_bias = s->opt_phase_bias; d.extend_refill_min = s->opt_extend_refill; d.extend_inner_min = s->opt_extend_inner;
     if ((rc = s->w_stats.ensure(ST_COUNT))) return rc;
     HIP_TRY(hipMemset(s->w_stats.p, 0, ST_COUNT * sizeof(unsigned long long)));
     s->uploaded = true;
@@ -743,7 +743,13 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
                 }
                 const uint32_t g = grid_for(s, pc.npaths);
                 begin_timing(s, stream, 0, &ev);
-                if (s->opt_stats) hipLaunchKernelGGL(k_extend<true>, dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                if (s->opt_extend_persist && (level > 0 || s->opt_extend_persist > 1)) {
+                    // after the first bounce: persistent waves that refill their idle lanes (k_extend_p); camera rays are coherent and stay with k_extend
+                    uint32_t gp = s->grid_max / 8u * s->opt_extend_grid;
+                    if (gp > g) gp = g;
+                    if (s->opt_stats) hipLaunchKernelGGL(k_extend_p<true>, dim3(gp), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                    else hipLaunchKernelGGL(k_extend_p<false>, dim3(gp), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                } else if (s->opt_stats) hipLaunchKernelGGL(k_extend<true>, dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
                 else hipLaunchKernelGGL(k_extend<false>, dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
                 end_timing(s, stream, ev);
                 begin_timing(s, stream, 2, &ev);
@@ -1117,6 +1123,10 @@ int rt_set_option(rt_scene* s, const char* name, uint64_t value) {
     else if (n == "light_waves") s->opt_light_waves = (uint32_t)value;
     else if (n == "refill_min") { s->opt_refill_min = value > 64 ? 64 : (value < 1 ? 1 : (uint32_t)value); s->dev.refill_min = s->opt_refill_min; }
     else if (n == "phase_bias") { s->opt_phase_bias = (uint32_t)value; s->dev.phase_bias = s->opt_phase_bias; }
+    else if (n == "extend_persist") s->opt_extend_persist = (uint32_t)value;
+    else if (n == "extend_refill") { s->opt_extend_refill = value > 64 ? 64 : (value < 1 ? 1 : (uint32_t)value); s->dev.extend_refill_min = s->opt_extend_refill; }
+    else if (n == "extend_inner") { s->opt_extend_inner = value > 64 ? 64 : (uint32_t)value; s->dev.extend_inner_min = s->opt_extend_inner; }
+    else if (n == "extend_grid") s->opt_extend_grid = value < 1 ? 1 : (uint32_t)value;
     else if (n == "inner_min") { s->opt_inner_min = value > 64 ? 64 : (uint32_t)value; s->dev.inner_min = s->opt_inner_min; }
     else return fail(RT_ERR_INVALID, "unknown option '" + n + "'");
     return RT_OK;

@@ -55,6 +55,8 @@ struct DevScene {
     const uint32_t* wrec;    // primitive record of each object in wprims (0xFFFFFFFF: emissive, not in the tree)
     uint32_t n_wnodes;       // 0: shadow rays take the binary tree
     uint32_t refill_min;     // k_trace_p: idle lanes that trigger a refill of the wave
+    uint32_t extend_refill_min;   // k_extend_p: the same for closest-hit rays
+    uint32_t extend_inner_min;    // k_extend_p: lanes at an inner node below which the wave turns to the waiting leaf tests (sc.inner_min of traverse())
     uint32_t phase_bias;     // k_trace_p: node step when 4 * lanes_at_nodes >= phase_bias * lanes_at_primitives
 };
 
@@ -848,6 +850,117 @@ __global__ void __launch_bounds__(RT_BLOCK, 8) k_extend(DevScene sc, PassCtx pc,
     }
     flush_stats<STATS>(pc.stats, tst, ST_C_INNER);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&pc.stats[ST_RAYS_CLOSEST], (unsigned long long)n);
+}
+
+// Scene::intersect for the ray queue as a persistent wave loop: the traversal of traverse<0> (same tree, same tests, same pruning and
+// tie-break: the result of a ray does not depend on what the other lanes do), but a wave keeps going through rows of 64 rays and hands
+// new rays to the lanes whose ray has finished, instead of waiting for the longest ray of every row.  After the first bounce rays of a row
+// have little in common and their traversal lengths differ several-fold, which left k_extend at 0.23-0.29 of its lanes.
+template <bool STATS>
+__global__ void __launch_bounds__(RT_BLOCK, 8) k_extend_p(DevScene sc, PassCtx pc, uint32_t level) {
+    RT_STACK_DECL;
+    TravStats tst = {0, 0, 0, 0, 0};
+    const uint32_t n = (sc.n_tri + sc.n_sph == 0) ? 0u : pc.counts[level];
+    const float4* ro = pc.ray_o[level & 1];
+    const float4* rd = pc.ray_d[level & 1];
+    const uint32_t n_waves = gridDim.x * (RT_BLOCK / 64);
+    const uint32_t inner_min = sc.extend_inner_min, refill_min = sc.extend_refill_min;
+    uint32_t next_row = __builtin_amdgcn_readfirstlane((blockIdx.x * RT_BLOCK + threadIdx.x) >> 6);   // rows of 64 rays: this wave's, then + n_waves
+    uint32_t pend_at = 0u, pend_end = 0u;                                     // rays of the current row not yet handed out
+    // the ray this lane is tracing (have)
+    bool have = false;
+    uint32_t e = 0u, cur = 0u, best_id = RT_MISS, best_rank = 0xFFFFFFFFu;
+    float best = __builtin_inff();
+    vec3 o = mk(0.0f, 0.0f, 0.0f), d = mk(0.0f, 0.0f, 1.0f);
+    BoxRay br = make_box_ray(o, d);
+    for (;;) {
+        const unsigned long long idle = __ballot(!have);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        const bool more = pend_at < pend_end || (unsigned long long)next_row * 64ull < n;
+        if (more && n_idle >= refill_min) {
+            if (pend_at == pend_end) {
+                pend_at = next_row * 64u;
+                pend_end = n - pend_at < 64u ? n : pend_at + 64u;
+                next_row += n_waves;
+            }
+            const uint32_t take = pend_end - pend_at < n_idle ? pend_end - pend_at : n_idle;
+            const uint32_t irank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            if (!have && irank < take) {
+                e = pend_at + irank;
+                o = xyz(ro[e]); d = xyz(rd[e]);
+                br = make_box_ray(o, d);
+                best = __builtin_inff(); best_id = RT_MISS; best_rank = 0xFFFFFFFFu;
+                st.sp = 0;
+                cur = sc.root;
+                have = true;
+            }
+            pend_at += take;
+            continue;
+        }
+        if (n_idle == 64u) break;
+        bool done = !have;
+        for (;;) {
+            const bool at_inner = !done && !(cur & LEAF_BIT);
+            const unsigned long long mi = __ballot(at_inner);
+            if (!mi) break;
+            if ((uint32_t)__popcll(mi) < inner_min && __ballot(!done && (cur & LEAF_BIT)) != 0ull) break;
+            if (more && (uint32_t)__popcll(__ballot(done)) >= refill_min) break;      // enough lanes have run dry: hand out new rays first
+            if (at_inner) {
+                const float4* np = sc.nodes + 4 * (size_t)cur;
+                const float4 a = np[0], b = np[1], c = np[2], k = np[3];
+                if (STATS) tst.inner++;
+                float tl, tr;
+                bool hl = slab(br, a.x, a.y, a.z, a.w, b.x, b.y, &tl);
+                bool hr = slab(br, b.z, b.w, c.x, c.y, c.z, c.w, &tr);
+                const float lim = prune_limit(best);
+                const uint32_t left = __float_as_uint(k.x), right = __float_as_uint(k.y), fragile = __float_as_uint(k.z);
+                hl = hl && (!(tl > lim) || (fragile & 1u));
+                hr = hr && (!(tr > lim) || (fragile & 2u));
+                if (hl && hr) {
+                    const bool left_first = !(tr < tl);
+                    st.push(left_first ? right : left);
+                    cur = left_first ? left : right;
+                } else if (hl) {
+                    cur = left;
+                } else if (hr) {
+                    cur = right;
+                } else if (st.sp == 0) {
+                    done = true;
+                } else {
+                    cur = st.pop();
+                }
+            }
+        }
+        if (!done && (cur & LEAF_BIT)) {
+            const uint32_t obj = cur & OBJECT_MASK;
+            float t;
+            bool ok;
+            uint32_t rank;
+            if (obj < sc.n_tri) {
+                const float4* tp = sc.tris + 3 * (size_t)obj;
+                const float4 A = tp[0], B = tp[1], C = tp[2];
+                if (STATS) tst.tris++;
+                ok = hit_triangle(xyz(A), xyz(B), xyz(C), o, d, &t);
+                rank = __float_as_uint(A.w);
+            } else {
+                if (STATS) tst.sphs++;
+                ok = hit_sphere(sc.sph[obj - sc.n_tri], o, d, &t);
+                rank = sc.sph_aux[obj - sc.n_tri].x;
+            }
+            if (ok && (t < best || (t == best && best_id != RT_MISS && rank < best_rank))) {
+                best = t; best_id = obj; best_rank = rank;
+            }
+            if (st.sp == 0) done = true;
+            else cur = st.pop();
+        }
+        if (have && done) {
+            pc.hit_id[e] = best_id;
+            pc.hit_t[e] = best;
+            have = false;
+        }
+    }
+    flush_stats<STATS>(pc.stats, tst, ST_C_INNER);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&pc.stats[ST_RAYS_CLOSEST], (unsigned long long)pc.counts[level]);
 }
 
 // cast_ray dispatch (src/raytracer.rs:337-349) up to the point where light sampling starts.

@@ -263,19 +263,21 @@ def test_two_lights_odd_sample_counts_and_moved_camera(gpu, w, h, spp, L, b, cam
 
 def test_occluder_cache_and_scheduling_switches_do_not_change_a_pixel(gpu):
     """The per-light occluder cache ("hot", fixed at the first render), the root-node test in k_light, the own-object test and the
-    scheduling constants of k_trace_p are search-order choices only: every combination gives the oracle's image and ray counts."""
+    scheduling constants of k_trace_p and k_extend_p (and whether closest-hit rays take the persistent kernel at all) are search-order choices only: every combination gives the oracle's image and ray counts."""
     op = oracle_params(width=56, height=48, spp=3, light_samples=6, bounces=5, seed=7)
     osc, gsc = _two_light_scene()
     ref = osc.render(op)
     p = to_rt_params(op)
     for opts in ({}, {"self_test": 0}, {"refill_min": 1, "phase_bias": 1}, {"refill_min": 64, "phase_bias": 16, "shadow_waves": 5},
-                 {"light_waves": 8}):
+                 {"light_waves": 8}, {"extend_persist": 0}, {"extend_persist": 2, "extend_refill": 1, "extend_inner": 1},
+                 {"extend_persist": 2, "extend_refill": 64, "extend_inner": 64, "extend_grid": 1}, {"extend_refill": 7, "extend_inner": 40, "extend_grid": 3}):
         for k, v in opts.items():
             gsc.set_option(k, v)
         got, cnt = gpu_render(gsc, p)
         assert np.array_equal(got, ref["rgba"]), opts
-        assert cnt["rays_shadow"] == ref["occluded_calls"], opts
-        for k, v in {"self_test": 1, "refill_min": 16, "phase_bias": 4, "shadow_waves": 8, "light_waves": 4}.items():
+        assert cnt["rays_shadow"] == ref["occluded_calls"] and cnt["rays_closest"] == ref["intersect_calls"], opts
+        for k, v in {"self_test": 1, "refill_min": 16, "phase_bias": 4, "shadow_waves": 8, "light_waves": 4, "extend_persist": 1, "extend_refill": 24,
+                     "extend_inner": 20, "extend_grid": 8}.items():
             gsc.set_option(k, v)
     with pytest.raises(Exception):
         gsc.set_option("hot", 0)                           # the cache is chosen at the first render
