@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librustracer_hip.so")
+LIB_PATH = os.environ.get("RUSTRACER_HIP_LIB") or os.path.join(_HERE, "librustracer_hip.so")   # the override serves A/B builds (tools/build_variant.sh)
 
 RT_OK, RT_ERR_INVALID, RT_ERR_UNSUPPORTED, RT_ERR_HIP, RT_ERR_INTERRUPTED, RT_ERR_LIMIT = range(6)
 RT_BSDF_DIFFUSE, RT_BSDF_SPECULAR = 0, 1

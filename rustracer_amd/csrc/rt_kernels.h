@@ -1382,7 +1382,15 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
 }
 
 // The rest of one_bounce_radiance_importance and global_illumination (src/raytracer.rs:282-326).
-__global__ void __launch_bounds__(RT_BLOCK) k_shade_b(DevScene sc, PassCtx pc, uint32_t level) {
+// k_shade_b waits on memory (VALU 0.3 busy): 8 resident waves per SIMD with 4 light-sample records in flight per lane beat 4 waves with 8
+// (a 64-register budget, 52 B of spills): 21.7 -> 19.8 ms per 16-spp frame of config 4.
+#ifndef RT_SB_WAVES
+#define RT_SB_WAVES 8
+#endif
+#ifndef RT_SB_BATCH
+#define RT_SB_BATCH 4
+#endif
+__global__ void __launch_bounds__(RT_BLOCK, RT_SB_WAVES) k_shade_b(DevScene sc, PassCtx pc, uint32_t level) {
     const uint32_t n = pc.vcounts[level];
     const uint32_t bounces_left = pc.P.bounces - level;
     float4* no = pc.ray_o[(level + 1) & 1];
@@ -1398,10 +1406,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_b(DevScene sc, PassCtx pc, u
         if (e < n) {
             const float4 N4 = pc.vN[e];
             {
-                const float4 P4 = pc.vP[e], S4 = pc.vS[e];
-                const uint32_t slot = __float_as_uint(S4.x);
+                const float4 P4 = pc.vP[e];
                 const uint32_t mat = __float_as_uint(P4.w);
-                const float4 m0 = sc.mats[2 * mat], m1 = sc.mats[2 * mat + 1];
+                const float4 m0 = sc.mats[2 * mat];
                 const vec3 p = xyz(P4), nrm = xyz(N4);
                 vec3 l = mk(0.0f, 0.0f, 0.0f);
                 if (pc.persist) {
@@ -1422,14 +1429,14 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_b(DevScene sc, PassCtx pc, u
                         vec3 color = mk(0.0f, 0.0f, 0.0f);
                         const size_t row0 = ls_slot(e & ~63u, g * L, pc.nlL);                                  // first slot of the row of sample s: + 64 s
                         const unsigned long long* mrow = pc.tmask + (size_t)(e >> 6) * pc.nlL + (size_t)g * L;  // mask of that row: + s
-                        for (uint32_t s0 = 0; s0 < L; s0 += 8) {                         // 8 samples in flight, then added in sample order
-                            unsigned long long mk8[8];
-                            uint32_t w[8];
-                            float4 r[8];
+                        for (uint32_t s0 = 0; s0 < L; s0 += RT_SB_BATCH) {                         // RT_SB_BATCH samples in flight, then added in sample order
+                            unsigned long long mk8[RT_SB_BATCH];
+                            uint32_t w[RT_SB_BATCH];
+                            float4 r[RT_SB_BATCH];
 #pragma unroll
-                            for (uint32_t k = 0; k < 8; ++k) mk8[k] = s0 + k < L ? mrow[s0 + k] : 0ull;
+                            for (uint32_t k = 0; k < RT_SB_BATCH; ++k) mk8[k] = s0 + k < L ? mrow[s0 + k] : 0ull;
 #pragma unroll
-                            for (uint32_t k = 0; k < 8; ++k) {
+                            for (uint32_t k = 0; k < RT_SB_BATCH; ++k) {
                                 w[k] = RT_LR_BLOCKED;
                                 r[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                                 if ((mk8[k] >> lane) & 1ull) {
@@ -1439,7 +1446,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_b(DevScene sc, PassCtx pc, u
                                 }
                             }
 #pragma unroll
-                            for (uint32_t k = 0; k < 8; ++k)
+                            for (uint32_t k = 0; k < RT_SB_BATCH; ++k)
                                 if (!(w[k] & RT_LR_BLOCKED)) {
                                     const float d_s = r[k].w;
                                     const float num = num0 - d_s * d_s;
@@ -1464,6 +1471,10 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_b(DevScene sc, PassCtx pc, u
                         l = add(l, scale(color, inv_light_samples));                // raytracer.rs:282
                     }
                 }
+                // (what only the rest needs is fetched here, after the sample loop: k_shade_b waits on memory, and registers held across
+                // the loop cost it resident waves)
+                const float4 S4 = pc.vS[e], m1 = sc.mats[2 * mat + 1];
+                const uint32_t slot = __float_as_uint(S4.x);
                 l = add(l, xyz(m1));                                                // raytracer.rs:284
                 if (bounces_left == 1) {
                     fold_path(pc, slot, level, l);                                  // raytracer.rs:340-344
