@@ -162,6 +162,9 @@ int rt_get_counters(const rt_scene* scene, rt_counters* out);
  *   "wide" 0/1 is_occluded rays use the 8-wide occlusion BVH (default 1); "persist" 0/1 light samples go through the
  *   k_light + persistent k_trace_p pair (default 1); "hot" 0/1 per-light occluder cache (default 1; only before the first
  *   render); "self_test" 0/1 test the object a shadow ray starts on first (default 1);
+ *   "lanes" 1..4 (default 3) render lanes: rt_render / rt_render_device without progress and interrupt words cut the owned pixels into
+ *   that many ranges and render them concurrently on internal streams (joined to the caller's stream before the call returns its
+ *   work to it), as long as each gets "lane_min_pixels" (65536) pixels; each lane has pass buffers of its own;
  *   "extend_persist" 0/1/2 Scene::intersect rays after the first bounce (2: camera rays too) go through the persistent
  *   k_extend_p, which refills finished lanes (default 1);
  *   "refill_min" (16), "phase_bias" (4), "shadow_waves" (8), "light_waves" (4), "inner_min" (12), "extend_refill" (24),

@@ -87,6 +87,26 @@ struct DevBuf {
     }
 };
 
+// Pass buffers of one render lane (rt_scene::ws).  A frame is rendered by up to RT_MAX_LANES lanes, each on its own HIP stream over its
+// own part of the owned pixels: the kernels that wait on memory in one lane (k_shade_*, k_extend_p) run under the VALU-bound ones of
+// the other (k_light, k_trace_p).  Grow-only; no allocation in steady state.
+#define RT_MAX_LANES 4
+struct Workspace {
+    DevBuf<uint32_t> counts, hit_id, blist;
+    DevBuf<float> hit_t;
+    DevBuf<float4> ray_o[2], ray_d[2], vP, vN, vS, contrib, direct, stackA, stackB, radiance, lray, linv;
+    DevBuf<uint64_t> rng;
+    DevBuf<unsigned long long> tmask;
+    hipStream_t stream = nullptr;   // lanes run on these when there is more than one
+    hipEvent_t done = nullptr;
+    void release() {
+        counts.release(); hit_id.release(); blist.release(); hit_t.release();
+        for (int q = 0; q < 2; ++q) { ray_o[q].release(); ray_d[q].release(); }
+        vP.release(); vN.release(); vS.release(); contrib.release(); direct.release(); stackA.release(); stackB.release(); radiance.release();
+        lray.release(); linv.release(); rng.release(); tmask.release();
+    }
+};
+
 struct EventPair {
     hipEvent_t a, b;
     int cls;   // 0 closest, 1 shadow, 2 shade/other (k_binary too), 3 light sampling (k_light alone)
@@ -118,13 +138,9 @@ struct rt_scene {
     DevScene dev;
     uint64_t device_bytes = 0;
 
-    // workspace (grow-only; no allocation in steady state)
-    DevBuf<uint32_t> w_counts, w_hit_id, w_blist;
-    DevBuf<float> w_hit_t;
-    DevBuf<float4> w_ray_o[2], w_ray_d[2], w_vP, w_vN, w_vS, w_contrib, w_direct, w_stackA, w_stackB, w_radiance, w_accum;
-    DevBuf<float4> w_lray, w_linv;
-    DevBuf<uint64_t> w_rng;
-    DevBuf<unsigned long long> w_tmask;
+    Workspace ws[RT_MAX_LANES];                  // per-lane pass buffers
+    hipEvent_t ev_fork = nullptr;                // the caller's stream at the start of a multi-lane render
+    DevBuf<float4> w_accum;                      // per-pixel sums across sample chunks (lanes own disjoint pixels)
     DevBuf<ulonglong2> w_jump;
     uint32_t jump_nlL = 0xFFFFFFFFu;
     DevBuf<unsigned long long> w_stats;
@@ -135,7 +151,8 @@ struct rt_scene {
 
     bool opt_stats = false, opt_timing = false;
     uint64_t opt_max_paths = 1ull << 24;
-    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 16, opt_phase_bias = 4, opt_shadow_waves = 8, opt_light_waves = 4, opt_hot = 1, opt_extend_persist = 1, opt_extend_refill = 24, opt_extend_inner = 20, opt_extend_grid = 8;
+    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 16, opt_phase_bias = 4, opt_shadow_waves = 8, opt_light_waves = 4, opt_hot = 1, opt_extend_persist = 1, opt_extend_refill = 24, opt_extend_inner = 20, opt_extend_grid = 8, opt_lanes = 3;
+    uint64_t opt_lane_min_pixels = 65536;
     uint32_t grid_max = 2048;
 
     std::vector<EventPair> events;
@@ -347,7 +364,7 @@ int upload_scene(rt_scene* s) {
         if ((rc = s->d_wrec.ensure(s->wide.rec_of_obj.size()))) return rc;
         HIP_TRY(hipMemcpy(s->d_wrec.p, s->wide.rec_of_obj.data(), s->wide.rec_of_obj.size() * 4, hipMemcpyHostToDevice));
     }
-    if (ovf_rows && (rc = s->d_ovf.ensure((size_t)ovf_rows * s->grid_max * RT_BLOCK))) return rc;
+    if (ovf_rows && (rc = s->d_ovf.ensure((size_t)ovf_rows * s->grid_max * RT_BLOCK * RT_MAX_LANES))) return rc;   // one set of rows per render lane
     if (n_inner) {
         // device copy of the nodes: leaves of emissive objects carry NONBLOCK_BIT, word 14 the FRAGILE bits of the two subtrees
         std::vector<uint32_t> words(b.words);
@@ -650,15 +667,35 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
     const uint32_t levels = P.bounces + 1;
     const bool persist = !hemi && nlL > 0 && s->dev.n_wnodes != 0u && s->opt_persist;   // k_light + k_trace_p over the 8-wide occlusion BVH
     const bool in_wave = !persist && nlL > 0 && nlL <= 64 && (64 % nlL) == 0;
+
+    // Render lanes: the owned pixels are cut into n_lanes contiguous ranges, each rendered on a stream of its own with pass buffers of its
+    // own, so that the kernels of one lane that wait on memory overlap the VALU-bound ones of another.  Pixels are independent (RNG streams
+    // are keyed by pixel and sample, accumulators are per pixel), so the image does not depend on the number of lanes.  A caller that polls
+    // progress or may interrupt gets one lane on its own stream: the host then follows the render pass by pass and level by level.
+    uint32_t n_lanes = (progress || interrupt) ? 1u : s->opt_lanes;
+    if (n_lanes > RT_MAX_LANES) n_lanes = RT_MAX_LANES;
+    while (n_lanes > 1 && sh.n_own_pix / n_lanes < s->opt_lane_min_pixels) --n_lanes;
+    uint64_t lane_begin[RT_MAX_LANES + 1];
+    for (uint32_t k = 0; k <= n_lanes; ++k) lane_begin[k] = k == n_lanes ? sh.n_own_pix : (sh.n_own_pix * k / n_lanes) & ~(uint64_t)63;
+    uint64_t lane_pix = 0;   // the largest lane
+    for (uint32_t k = 0; k < n_lanes; ++k) lane_pix = lane_begin[k + 1] - lane_begin[k] > lane_pix ? lane_begin[k + 1] - lane_begin[k] : lane_pix;
+    if (n_lanes > 1) {
+        if (!s->ev_fork) HIP_TRY(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+        for (uint32_t k = 0; k < n_lanes; ++k) {
+            if (!s->ws[k].stream) HIP_TRY(hipStreamCreateWithFlags(&s->ws[k].stream, hipStreamNonBlocking));
+            if (!s->ws[k].done) HIP_TRY(hipEventCreateWithFlags(&s->ws[k].done, hipEventDisableTiming));
+        }
+    }
+
     uint32_t npix_chunk = 0, spc = 0;
-    // Workspace for `max_paths` camera samples in flight (about 1.8 KB each at 32 light samples, depth 8).  Grow-only; when the
+    // Workspace for `max_paths` camera samples in flight per lane (about 1.8 KB each at 32 light samples, depth 8).  Grow-only; when the
     // device cannot hold it the pass size is halved until it does (results do not depend on the pass size).
     for (uint64_t max_paths = s->opt_max_paths;; max_paths /= 2) {
         if (max_paths > cap_by_rays) max_paths = cap_by_rays;
         if (max_paths < 64) max_paths = 64;
-        if (sh.n_own_pix <= max_paths) {
-            npix_chunk = (uint32_t)sh.n_own_pix;
-            uint64_t k = max_paths / sh.n_own_pix;
+        if (lane_pix <= max_paths) {
+            npix_chunk = (uint32_t)lane_pix;
+            uint64_t k = max_paths / lane_pix;
             spc = (uint32_t)(k < P.spp ? k : P.spp);
         } else {
             npix_chunk = (uint32_t)max_paths;
@@ -667,140 +704,174 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
         const uint64_t cap_paths = (uint64_t)npix_chunk * spc;
         const uint64_t cap_slots = ((cap_paths + 63) / 64) * 64 * nlL;
         const uint64_t per_level = cap_paths * (P.bounces ? P.bounces : 1);
-        rc = s->w_counts.ensure(3 * (levels + 1));
-        for (int q = 0; q < 2 && !rc; ++q) {
-            rc = s->w_ray_o[q].ensure(cap_paths);
-            if (!rc) rc = s->w_ray_d[q].ensure(cap_paths);
+        rc = s->w_accum.ensure(sh.n_own_pix);
+        for (uint32_t k = 0; k < n_lanes && !rc; ++k) {
+            Workspace& w = s->ws[k];
+            rc = w.counts.ensure(3 * (levels + 1));
+            for (int q = 0; q < 2 && !rc; ++q) {
+                rc = w.ray_o[q].ensure(cap_paths);
+                if (!rc) rc = w.ray_d[q].ensure(cap_paths);
+            }
+            if (!rc) rc = w.hit_id.ensure(cap_paths);
+            if (!rc) rc = w.hit_t.ensure(cap_paths);
+            if (!rc) rc = w.vP.ensure(cap_paths);
+            if (!rc) rc = w.vN.ensure(cap_paths);
+            if (!rc) rc = w.vS.ensure(cap_paths);
+            if (!rc) rc = w.rng.ensure(cap_paths);
+            if (!rc && persist) rc = w.lray.ensure(cap_slots);
+            if (!rc && persist) rc = w.linv.ensure(cap_slots);
+            if (!rc && persist) rc = w.blist.ensure(cap_slots);
+            if (!rc && persist) rc = w.tmask.ensure(cap_slots / 64);
+            if (!rc && !persist && !in_wave) rc = w.contrib.ensure(cap_paths * (nlL ? nlL : 1));
+            if (!rc) rc = w.direct.ensure(cap_paths);
+            if (!rc) rc = w.stackA.ensure(per_level);
+            if (!rc) rc = w.stackB.ensure(per_level);
+            if (!rc) rc = w.radiance.ensure(cap_paths);
         }
-        if (!rc) rc = s->w_hit_id.ensure(cap_paths);
-        if (!rc) rc = s->w_hit_t.ensure(cap_paths);
-        if (!rc) rc = s->w_vP.ensure(cap_paths);
-        if (!rc) rc = s->w_vN.ensure(cap_paths);
-        if (!rc) rc = s->w_vS.ensure(cap_paths);
-        if (!rc) rc = s->w_rng.ensure(cap_paths);
-        if (!rc && persist) rc = s->w_lray.ensure(cap_slots);
-        if (!rc && persist) rc = s->w_linv.ensure(cap_slots);
-        if (!rc && persist) rc = s->w_blist.ensure(cap_slots);
-        if (!rc && persist) rc = s->w_tmask.ensure(cap_slots / 64);
-        if (!rc && !persist && !in_wave) rc = s->w_contrib.ensure(cap_paths * (nlL ? nlL : 1));
-        if (!rc) rc = s->w_direct.ensure(cap_paths);
-        if (!rc) rc = s->w_stackA.ensure(per_level);
-        if (!rc) rc = s->w_stackB.ensure(per_level);
-        if (!rc) rc = s->w_radiance.ensure(cap_paths);
-        if (!rc) rc = s->w_accum.ensure(sh.n_own_pix);
         if (!rc) break;
         (void)hipGetLastError();   // clear the out-of-memory error
         if (max_paths <= 65536) return rc;
         // the buffers that did fit at this size would compete with the smaller retry: give the whole workspace back first
-        HIP_TRY(hipStreamSynchronize(stream));
-        for (int q = 0; q < 2; ++q) { s->w_ray_o[q].release(); s->w_ray_d[q].release(); }
-        s->w_hit_id.release(); s->w_hit_t.release(); s->w_vP.release(); s->w_vN.release(); s->w_vS.release(); s->w_rng.release();
-        s->w_lray.release(); s->w_linv.release(); s->w_blist.release(); s->w_tmask.release(); s->w_contrib.release(); s->w_direct.release();
-        s->w_stackA.release(); s->w_stackB.release(); s->w_radiance.release(); s->w_accum.release();
+        HIP_TRY(hipDeviceSynchronize());
+        for (uint32_t k = 0; k < RT_MAX_LANES; ++k) s->ws[k].release();
+        s->w_accum.release();
     }
     if ((rc = ensure_jump(s, nlL, stream))) return rc;
 
-    PassCtx pc;
-    memset(&pc, 0, sizeof pc);
-    pc.P = P;
-    pc.seed_mixed = mix64(P.seed);
-    pc.tiles_x = sh.tiles_x; pc.n_tiles = sh.n_tiles;
-    pc.n_groups = n_groups; pc.nlL = nlL;
-    pc.counts = s->w_counts.p; pc.vcounts = s->w_counts.p + (levels + 1); pc.bcounts = s->w_counts.p + 2 * (levels + 1); pc.vS = s->w_vS.p;
-    for (int q = 0; q < 2; ++q) { pc.ray_o[q] = s->w_ray_o[q].p; pc.ray_d[q] = s->w_ray_d[q].p; }
-    pc.hit_id = s->w_hit_id.p; pc.hit_t = s->w_hit_t.p;
-    pc.vP = s->w_vP.p; pc.vN = s->w_vN.p; pc.rng = s->w_rng.p; pc.contrib = s->w_contrib.p; pc.direct = s->w_direct.p; pc.in_wave = in_wave ? 1u : 0u;
-    pc.lray = s->w_lray.p; pc.linv = s->w_linv.p; pc.blist = s->w_blist.p; pc.tmask = s->w_tmask.p; pc.persist = persist ? 1u : 0u;
-    pc.stackA = s->w_stackA.p; pc.stackB = s->w_stackB.p; pc.radiance = s->w_radiance.p; pc.accum = s->w_accum.p;
-    pc.jump = s->w_jump.p; pc.stats = s->w_stats.p; pc.rgba = rgba_dev;
-    pc.preview = (progress && host_rgba) ? 1u : 0u;
+    PassCtx pcs[RT_MAX_LANES];
+    DevScene devs[RT_MAX_LANES];
+    hipStream_t streams[RT_MAX_LANES];
+    for (uint32_t k = 0; k < n_lanes; ++k) {
+        Workspace& w = s->ws[k];
+        PassCtx& pc = pcs[k];
+        memset(&pc, 0, sizeof pc);
+        pc.P = P;
+        pc.seed_mixed = mix64(P.seed);
+        pc.tiles_x = sh.tiles_x; pc.n_tiles = sh.n_tiles;
+        pc.n_groups = n_groups; pc.nlL = nlL;
+        pc.counts = w.counts.p; pc.vcounts = w.counts.p + (levels + 1); pc.bcounts = w.counts.p + 2 * (levels + 1); pc.vS = w.vS.p;
+        for (int q = 0; q < 2; ++q) { pc.ray_o[q] = w.ray_o[q].p; pc.ray_d[q] = w.ray_d[q].p; }
+        pc.hit_id = w.hit_id.p; pc.hit_t = w.hit_t.p;
+        pc.vP = w.vP.p; pc.vN = w.vN.p; pc.rng = w.rng.p; pc.contrib = w.contrib.p; pc.direct = w.direct.p; pc.in_wave = in_wave ? 1u : 0u;
+        pc.lray = w.lray.p; pc.linv = w.linv.p; pc.blist = w.blist.p; pc.tmask = w.tmask.p; pc.persist = persist ? 1u : 0u;
+        pc.stackA = w.stackA.p; pc.stackB = w.stackB.p; pc.radiance = w.radiance.p; pc.accum = s->w_accum.p;
+        pc.jump = s->w_jump.p; pc.stats = s->w_stats.p; pc.rgba = rgba_dev;
+        pc.preview = (progress && host_rgba) ? 1u : 0u;
+        devs[k] = s->dev;
+        devs[k].ovf = s->d_ovf.p ? s->d_ovf.p + (size_t)k * s->ovf_rows * s->dev.ovf_stride : nullptr;   // concurrent kernels need rows of their own
+        streams[k] = n_lanes > 1 ? w.stream : stream;
+    }
+    if (n_lanes > 1) {
+        HIP_TRY(hipEventRecord(s->ev_fork, stream));
+        for (uint32_t k = 0; k < n_lanes; ++k) HIP_TRY(hipStreamWaitEvent(streams[k], s->ev_fork, 0));
+    }
 
-    const uint64_t n_pix_chunks = (sh.n_own_pix + npix_chunk - 1) / npix_chunk;
-    const uint64_t n_s_chunks = (P.spp + spc - 1) / spc;
-    const uint64_t total_passes = n_pix_chunks * n_s_chunks;
-    uint64_t done = 0;
-    for (uint64_t pix0 = 0; pix0 < sh.n_own_pix; pix0 += npix_chunk) {
-        const uint32_t npix = (uint32_t)((sh.n_own_pix - pix0) < npix_chunk ? (sh.n_own_pix - pix0) : npix_chunk);
-        for (uint32_t s0 = 0; s0 < P.spp; s0 += spc) {
+    // passes of a lane: its pixels in chunks of npix_chunk, the samples of a chunk in chunks of spc; lanes take turns at enqueueing a pass
+    uint64_t total_passes = 0, done = 0;
+    uint64_t at_pix[RT_MAX_LANES];
+    uint32_t at_s0[RT_MAX_LANES];
+    for (uint32_t k = 0; k < n_lanes; ++k) {
+        const uint64_t np = lane_begin[k + 1] - lane_begin[k];
+        total_passes += ((np + npix_chunk - 1) / npix_chunk) * ((P.spp + spc - 1) / spc);
+        at_pix[k] = lane_begin[k];
+        at_s0[k] = 0;
+    }
+    for (bool any = true; any;) {
+        any = false;
+        for (uint32_t k = 0; k < n_lanes; ++k) {
+            if (at_pix[k] >= lane_begin[k + 1]) continue;
+            any = true;
+            PassCtx& pc = pcs[k];
+            const DevScene& dv = devs[k];
+            const hipStream_t st = streams[k];
+            const uint64_t pix0 = at_pix[k];
+            const uint32_t s0 = at_s0[k];
+            const uint32_t npix = (uint32_t)((lane_begin[k + 1] - pix0) < npix_chunk ? (lane_begin[k + 1] - pix0) : npix_chunk);
+            const uint32_t spc_now = (P.spp - s0) < spc ? (P.spp - s0) : spc;
+            at_s0[k] += spc_now;
+            if (at_s0[k] >= P.spp) { at_s0[k] = 0; at_pix[k] += npix; }
             if (interrupt && *interrupt) {
-                HIP_TRY(hipStreamSynchronize(stream));
+                HIP_TRY(hipStreamSynchronize(st));
                 return fail(RT_ERR_INTERRUPTED, "render interrupted");
             }
-            const uint32_t spc_now = (P.spp - s0) < spc ? (P.spp - s0) : spc;
             pc.pix0 = (uint32_t)pix0; pc.npix = npix; pc.s0 = s0; pc.spc = spc_now; pc.npaths = npix * spc_now;
-            s->samples += 0;   // owned, valid samples are counted on the device side via ST_RAYS (primary level)
-            HIP_TRY(hipMemsetAsync(pc.counts, 0, 3 * (levels + 1) * sizeof(uint32_t), stream));
+            HIP_TRY(hipMemsetAsync(pc.counts, 0, 3 * (levels + 1) * sizeof(uint32_t), st));
             size_t ev;
-            begin_timing(s, stream, 2, &ev);
-            hipLaunchKernelGGL(k_generate, dim3(grid_for(s, pc.npaths)), dim3(RT_BLOCK), 0, stream, pc);
-            end_timing(s, stream, ev);
+            begin_timing(s, st, 2, &ev);
+            hipLaunchKernelGGL(k_generate, dim3(grid_for(s, pc.npaths)), dim3(RT_BLOCK), 0, st, pc);
+            end_timing(s, st, ev);
             for (uint32_t level = 0; level < levels; ++level) {
                 if (interrupt && level) {
                     // interrupt_render() (raytracer.rs:496-498) is honoured between bounce levels: the host waits for the level it
                     // has enqueued, so at most one level of one pass runs on after the flag is raised
-                    HIP_TRY(hipStreamSynchronize(stream));
+                    HIP_TRY(hipStreamSynchronize(st));
                     if (*interrupt) return fail(RT_ERR_INTERRUPTED, "render interrupted");
                 }
                 const uint32_t g = grid_for(s, pc.npaths);
-                begin_timing(s, stream, 0, &ev);
+                begin_timing(s, st, 0, &ev);
                 if (s->opt_extend_persist && (level > 0 || s->opt_extend_persist > 1)) {
                     // after the first bounce: persistent waves that refill their idle lanes (k_extend_p); camera rays are coherent and stay with k_extend
                     uint32_t gp = s->grid_max / 8u * s->opt_extend_grid;
                     if (gp > g) gp = g;
-                    if (s->opt_stats) hipLaunchKernelGGL(k_extend_p<true>, dim3(gp), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
-                    else hipLaunchKernelGGL(k_extend_p<false>, dim3(gp), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
-                } else if (s->opt_stats) hipLaunchKernelGGL(k_extend<true>, dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
-                else hipLaunchKernelGGL(k_extend<false>, dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
-                end_timing(s, stream, ev);
-                begin_timing(s, stream, 2, &ev);
-                hipLaunchKernelGGL(k_shade_a, dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
-                end_timing(s, stream, ev);
+                    if (s->opt_stats) hipLaunchKernelGGL(k_extend_p<true>, dim3(gp), dim3(RT_BLOCK), 0, st, dv, pc, level);
+                    else hipLaunchKernelGGL(k_extend_p<false>, dim3(gp), dim3(RT_BLOCK), 0, st, dv, pc, level);
+                } else if (s->opt_stats) hipLaunchKernelGGL(k_extend<true>, dim3(g), dim3(RT_BLOCK), 0, st, dv, pc, level);
+                else hipLaunchKernelGGL(k_extend<false>, dim3(g), dim3(RT_BLOCK), 0, st, dv, pc, level);
+                end_timing(s, st, ev);
+                begin_timing(s, st, 2, &ev);
+                hipLaunchKernelGGL(k_shade_a, dim3(g), dim3(RT_BLOCK), 0, st, dv, pc, level);
+                end_timing(s, st, ev);
                 if (level == P.bounces) break;
                 if (nlL) {
                     const uint32_t gs = grid_for(s, (uint64_t)pc.npaths * nlL);
-                    begin_timing(s, stream, hemi ? 0 : (persist ? 3 : 1), &ev);
+                    begin_timing(s, st, hemi ? 0 : (persist ? 3 : 1), &ev);
                     if (persist) {
-                        if (s->opt_stats) hipLaunchKernelGGL((k_light<true, 4>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level, s->hot_table);
-                        else if (s->opt_light_waves >= 8) hipLaunchKernelGGL((k_light<false, 8>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level, s->hot_table);
-                        else if (s->opt_light_waves >= 6) hipLaunchKernelGGL((k_light<false, 6>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level, s->hot_table);
-                        else if (s->opt_light_waves >= 5) hipLaunchKernelGGL((k_light<false, 5>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level, s->hot_table);
-                        else hipLaunchKernelGGL((k_light<false, 4>), dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level, s->hot_table);
-                        end_timing(s, stream, ev);
-                        begin_timing(s, stream, 2, &ev);
-                        if (s->opt_stats) hipLaunchKernelGGL(k_binary<true>, dim3(64), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
-                        else hipLaunchKernelGGL(k_binary<false>, dim3(64), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
-                        end_timing(s, stream, ev);
-                        begin_timing(s, stream, 1, &ev);
-                        if (s->opt_stats) hipLaunchKernelGGL((k_trace_p<true, 8>), dim3(gs), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
-                        else if (s->opt_shadow_waves >= 8) hipLaunchKernelGGL((k_trace_p<false, 8>), dim3(gs), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
-                        else if (s->opt_shadow_waves >= 6) hipLaunchKernelGGL((k_trace_p<false, 6>), dim3(gs), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
-                        else hipLaunchKernelGGL((k_trace_p<false, 5>), dim3(gs), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                        if (s->opt_stats) hipLaunchKernelGGL((k_light<true, 4>), dim3(g), dim3(RT_BLOCK), 0, st, dv, pc, level, s->hot_table);
+                        else if (s->opt_light_waves >= 8) hipLaunchKernelGGL((k_light<false, 8>), dim3(g), dim3(RT_BLOCK), 0, st, dv, pc, level, s->hot_table);
+                        else if (s->opt_light_waves >= 6) hipLaunchKernelGGL((k_light<false, 6>), dim3(g), dim3(RT_BLOCK), 0, st, dv, pc, level, s->hot_table);
+                        else if (s->opt_light_waves >= 5) hipLaunchKernelGGL((k_light<false, 5>), dim3(g), dim3(RT_BLOCK), 0, st, dv, pc, level, s->hot_table);
+                        else hipLaunchKernelGGL((k_light<false, 4>), dim3(g), dim3(RT_BLOCK), 0, st, dv, pc, level, s->hot_table);
+                        end_timing(s, st, ev);
+                        begin_timing(s, st, 2, &ev);
+                        if (s->opt_stats) hipLaunchKernelGGL(k_binary<true>, dim3(64), dim3(RT_BLOCK), 0, st, dv, pc, level);
+                        else hipLaunchKernelGGL(k_binary<false>, dim3(64), dim3(RT_BLOCK), 0, st, dv, pc, level);
+                        end_timing(s, st, ev);
+                        begin_timing(s, st, 1, &ev);
+                        if (s->opt_stats) hipLaunchKernelGGL((k_trace_p<true, 8>), dim3(gs), dim3(RT_BLOCK), 0, st, dv, pc, level);
+                        else if (s->opt_shadow_waves >= 8) hipLaunchKernelGGL((k_trace_p<false, 8>), dim3(gs), dim3(RT_BLOCK), 0, st, dv, pc, level);
+                        else if (s->opt_shadow_waves >= 6) hipLaunchKernelGGL((k_trace_p<false, 6>), dim3(gs), dim3(RT_BLOCK), 0, st, dv, pc, level);
+                        else hipLaunchKernelGGL((k_trace_p<false, 5>), dim3(gs), dim3(RT_BLOCK), 0, st, dv, pc, level);
                     } else if (hemi) {
-                        if (s->opt_stats) hipLaunchKernelGGL((k_shadow<true, true>), dim3(gs), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
-                        else hipLaunchKernelGGL((k_shadow<false, true>), dim3(gs), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                        if (s->opt_stats) hipLaunchKernelGGL((k_shadow<true, true>), dim3(gs), dim3(RT_BLOCK), 0, st, dv, pc, level);
+                        else hipLaunchKernelGGL((k_shadow<false, true>), dim3(gs), dim3(RT_BLOCK), 0, st, dv, pc, level);
                     } else {
-                        if (s->opt_stats) hipLaunchKernelGGL((k_shadow<true, false>), dim3(gs), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
-                        else hipLaunchKernelGGL((k_shadow<false, false>), dim3(gs), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
+                        if (s->opt_stats) hipLaunchKernelGGL((k_shadow<true, false>), dim3(gs), dim3(RT_BLOCK), 0, st, dv, pc, level);
+                        else hipLaunchKernelGGL((k_shadow<false, false>), dim3(gs), dim3(RT_BLOCK), 0, st, dv, pc, level);
                     }
-                    end_timing(s, stream, ev);
+                    end_timing(s, st, ev);
                 }
-                begin_timing(s, stream, 2, &ev);
-                hipLaunchKernelGGL(k_shade_b, dim3(g), dim3(RT_BLOCK), 0, stream, s->dev, pc, level);
-                end_timing(s, stream, ev);
+                begin_timing(s, st, 2, &ev);
+                hipLaunchKernelGGL(k_shade_b, dim3(g), dim3(RT_BLOCK), 0, st, dv, pc, level);
+                end_timing(s, st, ev);
             }
-            begin_timing(s, stream, 2, &ev);
-            hipLaunchKernelGGL(k_resolve, dim3(grid_for(s, pc.npix)), dim3(RT_BLOCK), 0, stream, pc);
-            end_timing(s, stream, ev);
+            begin_timing(s, st, 2, &ev);
+            hipLaunchKernelGGL(k_resolve, dim3(grid_for(s, pc.npix)), dim3(RT_BLOCK), 0, st, pc);
+            end_timing(s, st, ev);
             HIP_TRY(hipGetLastError());
             ++done;
-            if (progress || interrupt) {
-                HIP_TRY(hipStreamSynchronize(stream));
+            if (progress || interrupt) {      // (one lane, on the caller's stream)
+                HIP_TRY(hipStreamSynchronize(st));
                 if (pc.preview && done < total_passes)
                     HIP_TRY(hipMemcpy(host_rgba, rgba_dev, (size_t)P.width * P.height * 4, hipMemcpyDeviceToHost));
                 if (progress) *progress = (uint32_t)((float)done / (float)total_passes * 100.0f);   // raytracer.rs:191, 213
             }
         }
     }
+    if (n_lanes > 1)
+        for (uint32_t k = 0; k < n_lanes; ++k) {
+            HIP_TRY(hipEventRecord(s->ws[k].done, streams[k]));
+            HIP_TRY(hipStreamWaitEvent(stream, s->ws[k].done, 0));
+        }
     // samples = owned valid pixels * spp (host arithmetic; edge tiles are clipped)
     {
         uint64_t valid = 0;
@@ -901,10 +972,13 @@ void rt_scene_destroy(rt_scene* s) {
     if (s->uploaded) (void)hipDeviceSynchronize();
     s->d_nodes.release(); s->d_tris.release(); s->d_tri_nrm.release(); s->d_sph.release(); s->d_mats.release();
     s->d_sph_aux.release(); s->d_lights.release(); s->d_ovf.release(); s->d_wnodes.release(); s->d_wprims.release(); s->d_wrec.release();
-    s->w_counts.release(); s->w_hit_id.release(); s->w_blist.release(); s->w_hit_t.release();
-    for (int q = 0; q < 2; ++q) { s->w_ray_o[q].release(); s->w_ray_d[q].release(); }
-    s->w_vP.release(); s->w_vN.release(); s->w_vS.release(); s->w_contrib.release(); s->w_direct.release(); s->w_stackA.release(); s->w_stackB.release();
-    s->w_radiance.release(); s->w_accum.release(); s->w_tmask.release(); s->w_lray.release(); s->w_linv.release(); s->w_rng.release(); s->w_jump.release(); s->w_stats.release();
+    for (int k = 0; k < RT_MAX_LANES; ++k) {
+        s->ws[k].release();
+        if (s->ws[k].stream) (void)hipStreamDestroy(s->ws[k].stream);
+        if (s->ws[k].done) (void)hipEventDestroy(s->ws[k].done);
+    }
+    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+    s->w_accum.release(); s->w_jump.release(); s->w_stats.release();
     s->w_frame.release(); s->w_ids.release(); s->w_ts.release(); s->w_rays.release();
     for (size_t i = 0; i < s->events.size(); ++i) { (void)hipEventDestroy(s->events[i].a); (void)hipEventDestroy(s->events[i].b); }
     delete s;
@@ -1123,6 +1197,8 @@ int rt_set_option(rt_scene* s, const char* name, uint64_t value) {
     else if (n == "light_waves") s->opt_light_waves = (uint32_t)value;
     else if (n == "refill_min") { s->opt_refill_min = value > 64 ? 64 : (value < 1 ? 1 : (uint32_t)value); s->dev.refill_min = s->opt_refill_min; }
     else if (n == "phase_bias") { s->opt_phase_bias = (uint32_t)value; s->dev.phase_bias = s->opt_phase_bias; }
+    else if (n == "lane_min_pixels") s->opt_lane_min_pixels = value < 64 ? 64 : value;
+    else if (n == "lanes") s->opt_lanes = value < 1 ? 1 : (value > RT_MAX_LANES ? RT_MAX_LANES : (uint32_t)value);
     else if (n == "extend_persist") s->opt_extend_persist = (uint32_t)value;
     else if (n == "extend_refill") { s->opt_extend_refill = value > 64 ? 64 : (value < 1 ? 1 : (uint32_t)value); s->dev.extend_refill_min = s->opt_extend_refill; }
     else if (n == "extend_inner") { s->opt_extend_inner = value > 64 ? 64 : (uint32_t)value; s->dev.extend_inner_min = s->opt_extend_inner; }

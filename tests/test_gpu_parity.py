@@ -293,6 +293,30 @@ def test_occluder_cache_and_scheduling_switches_do_not_change_a_pixel(gpu):
     assert 0 < c_hot["trace_steps"][5] < c_cold["trace_steps"][5]      # rays handed to k_trace_p: fewer with the cache
 
 
+def test_render_lanes_do_not_change_a_pixel(scenes):
+    """rt_render without progress / interrupt words cuts the owned pixels into up to 4 lanes that render concurrently on streams of their own
+    (pass buffers and traversal-stack rows per lane).  Pixels are independent, so image and ray counts must equal the oracle's for any number
+    of lanes, any pass size, sharded or not, with the importance and the hemisphere estimator, and with a polling caller (one lane)."""
+    import rustracer_amd as ra
+    osc, gsc = scenes("dragon_small")
+    gsc.set_option("lane_min_pixels", 64)
+    try:
+        for est, shard, (w, h) in ((0, (0, 1), (150, 90)), (1, (0, 1), (97, 61)), (0, (1, 3), (160, 128))):
+            op = oracle_params(width=w, height=h, spp=5, light_samples=4, bounces=4, seed=123, direct_estimator=est, tile=(32, 32), shard=shard)
+            ref = osc.render(op)
+            p = to_rt_params(op)
+            for lanes, max_paths in ((1, 0), (2, 0), (3, 4096), (4, 1000), (4, 0)):
+                gsc.set_option("lanes", lanes)
+                gsc.set_option("max_paths", max_paths)
+                got, cnt = gpu_render(gsc, p)
+                assert np.array_equal(got, ref["rgba"]), (est, shard, lanes, max_paths, int((got != ref["rgba"]).sum()))
+                assert cnt["rays_closest"] == ref["intersect_calls"] and cnt["rays_shadow"] == ref["occluded_calls"], (est, shard, lanes, max_paths)
+    finally:
+        gsc.set_option("lanes", 3)
+        gsc.set_option("max_paths", 0)
+        gsc.set_option("lane_min_pixels", 65536)
+
+
 def test_occluder_cache_with_a_sphere_next_to_the_lamp(gpu):
     """The cache's sphere arm: a diffuse ball hangs right under the lamp of the sphere-on-plane scene (their boxes overlap, so it is
     the lamp's cached occluder) and shadows most of the plane; images with the cache on and off equal the oracle's."""
