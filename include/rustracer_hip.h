@@ -124,11 +124,12 @@ int rt_scene_wide_bvh(const rt_scene* scene, uint32_t* node_words, float* prim_r
  * rgba: width*height*4 bytes, row-major, top row first, alpha 255 (SharedPixelBuffer,
  * src/raytracer.rs:22-51); only owned pixels are written.
  * rt_render: rgba is host memory; blocks; progress (0..100, src/raytracer.rs:79) and interrupt may be NULL.  With a progress word the
- * host buffer is refreshed after every pass (a chunk of pixels x a chunk of samples): finished pixels appear chunk by chunk as the
- * reference's columns do (src/raytracer.rs:203-214), and a pixel whose samples are spread over several passes shows the mean of the samples
- * done so far (= the reference's image at that many spp), so a canvas polling the buffer (src/canvas.rs:179) sees the frame refine.  *interrupt is
- * polled between passes and, inside a pass, between bounce levels (the reference polls per pixel, src/raytracer.rs:184-204):
- * a render stops within one bounce level of one pass of raising it.
+ * host buffer is refreshed after every round of passes (a pass = a chunk of pixels x a chunk of samples; a round = one pass per render
+ * lane, see rt_set_option "lanes"): finished pixels appear chunk by chunk as the reference's columns do (src/raytracer.rs:203-214), and a
+ * pixel whose samples are spread over several passes shows the mean of the samples done so far (= the reference's image at that many
+ * spp), so a canvas polling the buffer (src/canvas.rs:179) sees the frame refine.  *interrupt is polled between rounds (the reference
+ * polls per pixel, src/raytracer.rs:184-204): a render stops within one round of raising it (about 0.1 s at 1920x1080 with 871,200
+ * triangles); with "lanes" = 1 it is also polled between the bounce levels of a pass, and stops within one level (a few ms).
  * rt_render_device: rgba is device memory; work is enqueued on `stream` (hipStream_t, may be NULL)
  * and the call returns without synchronising. */
 int rt_render(rt_scene* scene, const rt_render_params* params, uint8_t* rgba,
@@ -162,7 +163,7 @@ int rt_get_counters(const rt_scene* scene, rt_counters* out);
  *   "wide" 0/1 is_occluded rays use the 8-wide occlusion BVH (default 1); "persist" 0/1 light samples go through the
  *   k_light + persistent k_trace_p pair (default 1); "hot" 0/1 per-light occluder cache (default 1; only before the first
  *   render); "self_test" 0/1 test the object a shadow ray starts on first (default 1);
- *   "lanes" 1..4 (default 3) render lanes: rt_render / rt_render_device without progress and interrupt words cut the owned pixels into
+ *   "lanes" 1..4 (default 3) render lanes: rt_render / rt_render_device cut the owned pixels into
  *   that many ranges and render them concurrently on internal streams (joined to the caller's stream before the call returns its
  *   work to it), as long as each gets "lane_min_pixels" (65536) pixels; each lane has pass buffers of its own;
  *   "extend_persist" 0/1/2 Scene::intersect rays after the first bounce (2: camera rays too) go through the persistent

@@ -670,9 +670,10 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
 
     // Render lanes: the owned pixels are cut into n_lanes contiguous ranges, each rendered on a stream of its own with pass buffers of its
     // own, so that the kernels of one lane that wait on memory overlap the VALU-bound ones of another.  Pixels are independent (RNG streams
-    // are keyed by pixel and sample, accumulators are per pixel), so the image does not depend on the number of lanes.  A caller that polls
-    // progress or may interrupt gets one lane on its own stream: the host then follows the render pass by pass and level by level.
-    uint32_t n_lanes = (progress || interrupt) ? 1u : s->opt_lanes;
+    // are keyed by pixel and sample, accumulators are per pixel), so the image does not depend on the number of lanes.  For a caller that
+    // polls progress or may interrupt, the host waits after every round (one pass per lane) to report and to look at the flag; with one lane
+    // ("lanes" = 1) it also looks between bounce levels.
+    uint32_t n_lanes = s->opt_lanes;
     if (n_lanes > RT_MAX_LANES) n_lanes = RT_MAX_LANES;
     while (n_lanes > 1 && sh.n_own_pix / n_lanes < s->opt_lane_min_pixels) --n_lanes;
     uint64_t lane_begin[RT_MAX_LANES + 1];
@@ -778,6 +779,10 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
     }
     for (bool any = true; any;) {
         any = false;
+        if (interrupt && *interrupt && done < total_passes) {   // between rounds: every lane has finished the same number of passes
+            for (uint32_t j = 0; j < n_lanes; ++j) HIP_TRY(hipStreamSynchronize(streams[j]));
+            return fail(RT_ERR_INTERRUPTED, "render interrupted");
+        }
         for (uint32_t k = 0; k < n_lanes; ++k) {
             if (at_pix[k] >= lane_begin[k + 1]) continue;
             any = true;
@@ -790,10 +795,6 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
             const uint32_t spc_now = (P.spp - s0) < spc ? (P.spp - s0) : spc;
             at_s0[k] += spc_now;
             if (at_s0[k] >= P.spp) { at_s0[k] = 0; at_pix[k] += npix; }
-            if (interrupt && *interrupt) {
-                HIP_TRY(hipStreamSynchronize(st));
-                return fail(RT_ERR_INTERRUPTED, "render interrupted");
-            }
             pc.pix0 = (uint32_t)pix0; pc.npix = npix; pc.s0 = s0; pc.spc = spc_now; pc.npaths = npix * spc_now;
             HIP_TRY(hipMemsetAsync(pc.counts, 0, 3 * (levels + 1) * sizeof(uint32_t), st));
             size_t ev;
@@ -801,7 +802,7 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
             hipLaunchKernelGGL(k_generate, dim3(grid_for(s, pc.npaths)), dim3(RT_BLOCK), 0, st, pc);
             end_timing(s, st, ev);
             for (uint32_t level = 0; level < levels; ++level) {
-                if (interrupt && level) {
+                if (interrupt && level && n_lanes == 1) {
                     // interrupt_render() (raytracer.rs:496-498) is honoured between bounce levels: the host waits for the level it
                     // has enqueued, so at most one level of one pass runs on after the flag is raised
                     HIP_TRY(hipStreamSynchronize(st));
@@ -859,12 +860,12 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
             end_timing(s, st, ev);
             HIP_TRY(hipGetLastError());
             ++done;
-            if (progress || interrupt) {      // (one lane, on the caller's stream)
-                HIP_TRY(hipStreamSynchronize(st));
-                if (pc.preview && done < total_passes)
-                    HIP_TRY(hipMemcpy(host_rgba, rgba_dev, (size_t)P.width * P.height * 4, hipMemcpyDeviceToHost));
-                if (progress) *progress = (uint32_t)((float)done / (float)total_passes * 100.0f);   // raytracer.rs:191, 213
-            }
+        }
+        if (any && (progress || interrupt)) {      // end of a round: one pass per lane is enqueued
+            for (uint32_t j = 0; j < n_lanes; ++j) HIP_TRY(hipStreamSynchronize(streams[j]));
+            if (progress && host_rgba && done < total_passes)
+                HIP_TRY(hipMemcpy(host_rgba, rgba_dev, (size_t)P.width * P.height * 4, hipMemcpyDeviceToHost));
+            if (progress) *progress = (uint32_t)((float)done / (float)total_passes * 100.0f);   // raytracer.rs:191, 213
         }
     }
     if (n_lanes > 1)

@@ -867,10 +867,12 @@ def test_native_rccl_gather_at_world_1(scenes):
         comm.destroy()
 
 
-def test_partial_frames_refine_and_equal_the_oracle_at_the_samples_done(scenes):
+@pytest.mark.parametrize("lanes", [1, 2])
+def test_partial_frames_refine_and_equal_the_oracle_at_the_samples_done(scenes, lanes):
     """Control surface (raytracer.rs:203-214, canvas.rs:179): while rt_render runs, the host buffer a canvas polls shows the frame fill and
     refine.  With the samples spread over passes of 3, the buffer after k passes is the mean of the first 3k samples of every pixel, which is
-    bit for bit the oracle's image at 3k spp; an interrupt leaves that partial frame in place; the finished frame equals the oracle at full spp."""
+    bit for bit the oracle's image at 3k spp; an interrupt leaves that partial frame in place; the finished frame equals the oracle at full spp.
+    With two render lanes a round is one pass of each lane over its half of the pixels: the same partial frames."""
     import threading
     from rustracer_amd._lib import RT_ERR_INTERRUPTED, lib, ptr
     osc, gsc = scenes("teapot")
@@ -878,7 +880,9 @@ def test_partial_frames_refine_and_equal_the_oracle_at_the_samples_done(scenes):
     kw = dict(width=W, height=H, light_samples=2, bounces=3)
     refs = {k: osc.render(oracle_params(spp=k, **kw))["rgba"] for k in range(CH, SPP + 1, CH)}
     p = to_rt_params(oracle_params(spp=SPP, **kw))
-    gsc.set_option("max_paths", W * H * CH)
+    gsc.set_option("max_paths", W * H // lanes * CH)
+    gsc.set_option("lanes", lanes)
+    gsc.set_option("lane_min_pixels", 64)
     try:
         rgba = np.zeros((H, W, 4), np.uint8)
         prog, intr = C.c_uint32(0), C.c_uint32(0)
@@ -900,8 +904,9 @@ def test_partial_frames_refine_and_equal_the_oracle_at_the_samples_done(scenes):
         # every snapshot taken at a pass boundary is one of the partial images (a snapshot may straddle a refresh: skip torn ones)
         whole = [s for _, s in seen if any(np.array_equal(s, r) for r in refs.values())]
         assert len(seen) == 0 or len(whole) >= 1
-        # deterministic form: interrupt after the first pass has been reported
-        for stop_at in (1, 2, 3):
+        # deterministic form: interrupt after the first pass has been reported.  One lane looks at the flag between bounce levels, so raising it
+        # after the third of four passes still stops the fourth; several lanes look between rounds only, and the last round may get through
+        for stop_at in ((1, 2, 3) if lanes == 1 else (1, 2)):
             rgba[:] = 0
             prog.value, intr.value = 0, 0
             box = {}
@@ -922,6 +927,8 @@ def test_partial_frames_refine_and_equal_the_oracle_at_the_samples_done(scenes):
             assert k_done and stop_at * CH <= k_done[0] < SPP, "the interrupted frame is not the oracle's image at a multiple of %d spp" % CH
     finally:
         gsc.set_option("max_paths", 0)
+        gsc.set_option("lanes", 3)
+        gsc.set_option("lane_min_pixels", 65536)
 
 
 @pytest.mark.parametrize("name", ["teapot", "specular", "dragon_small", "dragon_full", "chain"])
