@@ -148,6 +148,7 @@ def main():
     scene.set_option("timing", 0)
 
     cnt = scene.counters()   # counts and HIP-event kernel times of the last timed step of this rank
+    lanes = scene.get_option("lanes")
     el = torch.tensor([elapsed], dtype=torch.float64)
     tot = torch.tensor([cnt["rays_closest"], cnt["rays_shadow"], cnt["samples"]], dtype=torch.float64)
     if world > 1:
@@ -226,6 +227,19 @@ def main():
             "what": "Scene::intersect: closest hit on the binary SAH tree (while-while, rank tie-break)",
             "unit": "intersect ray", "bytes_per_unit": round(b_ext, 1), "units_per_launch": round(cnt["rays_closest"] / max(cnt["launches_closest"], 1), 1),
             "launches_per_step": int(cnt["launches_closest"]), "ms_per_step": round(cnt["kernel_ms_closest"], 2)}
+        # The timed steps run `lanes` render lanes on streams of their own: kernels of different lanes overlap, so a
+        # kernel's HIP-event duration in the timed region includes the time it shared the GPU, and the durations add up to more than the
+        # frame.  One more frame with a single lane gives every kernel's duration when it has the GPU to itself (`exclusive_*`).
+        ex = None
+        if lanes > 1:
+            scene.set_option("lanes", 1)
+            scene.set_option("timing", 1)
+            check(lib().rt_render_device(scene.handle, C.byref(params), frame.data_ptr(), stream))
+            torch.cuda.synchronize(dev)
+            ex = scene.counters()
+            scene.set_option("timing", 0)
+            scene.set_option("lanes", lanes)
+        ex_ms = {"k_trace_p": "kernel_ms_shadow", "k_shadow": "kernel_ms_shadow", "k_light": "kernel_ms_light", "k_extend": "kernel_ms_closest"}
         frame_ms = cnt["kernel_ms_shadow"] + cnt["kernel_ms_light"] + cnt["kernel_ms_closest"] + cnt["kernel_ms_shade"]
         pmc = pmc_kernels(a) if world == 1 else {}   # the committed counters are of the one-GPU launch sizes
         for name, k in kernels.items():
@@ -233,6 +247,9 @@ def main():
             k["share_of_kernel_time"] = round(k["ms_per_step"] / max(frame_ms, 1e-9), 4)
             k["achieved_GBps"] = round(k["bytes_per_unit"] * k["units_per_launch"] / max(k["avg_launch_ms"], 1e-9) / 1e6, 2)
             k["frac_of_hbm_peak"] = round(k["achieved_GBps"] / HBM_PEAK_GBS, 5)
+            if ex is not None:
+                k["exclusive_avg_launch_ms"] = round(ex[ex_ms[name]] / max(k["launches_per_step"], 1), 4)
+                k["exclusive_achieved_GBps"] = round(k["bytes_per_unit"] * k["units_per_launch"] / max(k["exclusive_avg_launch_ms"], 1e-9) / 1e6, 2)
             m = pmc.get(name, {}) if isinstance(pmc.get(name, {}), dict) else {}
             k["traffic"] = m.get("hbm_bytes_per_launch")
             for f in ("l2_hit_rate", "valu_issue_busy", "valu_active_lanes", "valu_insts_per_launch"):
@@ -246,6 +263,13 @@ def main():
             "traffic_GBps": (round(d["traffic"] / max(d["avg_launch_ms"], 1e-9) / 1e6, 1) if d.get("traffic") else None),
             "kernel": "%s (%s)" % (dom, d["what"]), "bytes_per_unit": d["bytes_per_unit"], "unit_of_work": d["unit"],
             "units_per_launch": d["units_per_launch"], "avg_launch_ms": d["avg_launch_ms"], "launches_per_step": d["launches_per_step"],
+            "render_lanes": lanes,
+            "exclusive": ({"avg_launch_ms": d["exclusive_avg_launch_ms"], "achieved": d["exclusive_achieved_GBps"],
+                           "frac": round(d["exclusive_achieved_GBps"] / HBM_PEAK_GBS, 5),
+                           "frame_ms_one_lane": round(ex["kernel_ms_shadow"] + ex["kernel_ms_light"] + ex["kernel_ms_closest"] + ex["kernel_ms_shade"], 2),
+                           "note": "the same kernel in a frame rendered with one lane (nothing else on the GPU); in the timed region %d lanes run "
+                                   "concurrently and a kernel's launch time includes the time it shared the GPU with the other lanes' kernels" % lanes}
+                          if ex is not None else None),
             "limiter": {"kind": "VALU issue", "valu_issue_busy": d.get("valu_issue_busy"), "valu_active_lanes": d.get("valu_active_lanes"),
                         "valu_insts_per_launch": d.get("valu_insts_per_launch"),
                         "note": "valu_issue_busy = fraction of all SIMD cycles of the kernel's run time with a VALU instruction executing "
@@ -273,7 +297,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[3]: dragon GI, %dx%d, %d spp, %d light samples, depth %d, 32x32 screen tiles over %d GPU(s)%s"
                    % (a.width, a.height, a.spp, a.light_samples, a.bounces, world, (" + native RCCL all-gather (rt_gather_tiles)" if comm is not None or world == 1 else " + gloo all_gather through the host") if world > 1 else ""),
-                   "mesh": "%s, %d triangles" % (mesh_label, n_tri - 10), "seed": a.seed, "scene_build_s": round(scene_s, 2)},
+                   "mesh": "%s, %d triangles" % (mesh_label, n_tri - 10), "seed": a.seed, "scene_build_s": round(scene_s, 2), "render_lanes": lanes},
         "samples_per_s": round(samples * a.steps / elapsed, 1),
         "rays_per_step": int(rays_per_step), "rays_closest_per_step": int(rays_closest), "rays_shadow_per_step": int(rays_shadow),
         "rays_per_sample": round(rays_per_step / max(samples, 1), 2),
@@ -281,6 +305,7 @@ def main():
         # settled by the test of the object the ray starts on and the per-light occluder cache, without a tree search.  This is the rate of
         # the rays that do search a tree (all intersect rays + the is_occluded rays k_trace_p traverses), world == 1 only.
         "traversed_Mrays_per_s": (round((rays_closest + traced_shadow_per_step) * a.steps / elapsed / 1e6, 2) if traced_shadow_per_step is not None else None),
+        # HIP-event kernel times of the last timed step, summed per class; with more than one render lane kernels overlap and the sum exceeds the frame
         "kernel_ms_last_step": {"trace_shadow": round(cnt["kernel_ms_shadow"], 2), "trace_closest": round(cnt["kernel_ms_closest"], 2),
                                 "light_sampling": round(cnt["kernel_ms_light"], 2), "shade_generate_resolve": round(cnt["kernel_ms_shade"], 2)},
         "roofline": roofline, "cpu_baseline": cpu,

@@ -171,6 +171,8 @@ int rt_get_counters(const rt_scene* scene, rt_counters* out);
  *   "refill_min" (16), "phase_bias" (4), "shadow_waves" (8), "light_waves" (4), "inner_min" (12), "extend_refill" (24),
  *   "extend_inner" (20), "extend_grid" (8 workgroups per CU): scheduling constants. */
 int rt_set_option(rt_scene* scene, const char* name, uint64_t value);
+/* The current value of an option of rt_set_option (no reference counterpart). */
+int rt_get_option(const rt_scene* scene, const char* name, uint64_t* value);
 
 /* Screen tiles (no reference counterpart): pack the owned tiles of a frame into a
  * compact buffer of n_owned_tiles(padded) * tile_w*tile_h*bytes_per_pixel and back.  Device pointers. */

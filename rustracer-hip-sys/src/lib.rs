@@ -137,6 +137,7 @@ extern "C" {
 
     pub fn rt_get_counters(scene: *const rt_scene, out: *mut rt_counters) -> c_int;
     pub fn rt_set_option(scene: *mut rt_scene, name: *const c_char, value: u64) -> c_int;
+    pub fn rt_get_option(scene: *const rt_scene, name: *const c_char, value: *mut u64) -> c_int;
 
     pub fn rt_tiles_per_shard(params: *const rt_render_params) -> u32;
     pub fn rt_tiles_pack(params: *const rt_render_params, frame_dev: *const c_void, compact_dev: *mut c_void, bytes_per_pixel: u32, stream: *mut c_void) -> c_int;

@@ -1209,6 +1209,20 @@ int rt_set_option(rt_scene* s, const char* name, uint64_t value) {
     return RT_OK;
 }
 
+int rt_get_option(const rt_scene* s, const char* name, uint64_t* value) {
+    if (!s || !name || !value) return fail(RT_ERR_INVALID, "NULL argument");
+    const std::string n(name);
+    const struct { const char* name; uint64_t v; } table[] = {
+        {"stats", s->opt_stats}, {"timing", s->opt_timing}, {"max_paths", s->opt_max_paths}, {"self_test", s->opt_self_test}, {"wide", s->opt_wide},
+        {"persist", s->opt_persist}, {"hot", s->opt_hot}, {"shadow_waves", s->opt_shadow_waves}, {"light_waves", s->opt_light_waves},
+        {"refill_min", s->opt_refill_min}, {"phase_bias", s->opt_phase_bias}, {"inner_min", s->opt_inner_min}, {"lanes", s->opt_lanes},
+        {"lane_min_pixels", s->opt_lane_min_pixels}, {"extend_persist", s->opt_extend_persist}, {"extend_refill", s->opt_extend_refill},
+        {"extend_inner", s->opt_extend_inner}, {"extend_grid", s->opt_extend_grid}};
+    for (const auto& e : table)
+        if (n == e.name) { *value = e.v; return RT_OK; }
+    return fail(RT_ERR_INVALID, "unknown option '" + n + "'");
+}
+
 uint32_t rt_tiles_per_shard(const rt_render_params* P) {
     if (!P || !P->tile_w || !P->tile_h || !P->shard_count) return 0;
     const uint32_t tiles = ((P->width + P->tile_w - 1) / P->tile_w) * ((P->height + P->tile_h - 1) / P->tile_h);

@@ -192,6 +192,11 @@ class Scene:
     def set_option(self, name, value):
         check(lib().rt_set_option(self.handle, name.encode(), int(value)))
 
+    def get_option(self, name):
+        v = C.c_uint64(0)
+        check(lib().rt_get_option(self.handle, name.encode(), C.byref(v)))
+        return int(v.value)
+
     def counters(self):
         c = _lib.Counters()
         check(lib().rt_get_counters(self.handle, C.byref(c)))
