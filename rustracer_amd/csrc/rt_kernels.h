@@ -156,28 +156,7 @@ __device__ __forceinline__ vec3 screen_to_world(const rt_render_params& P, uint3
 //             mantissa of b.
 //   sqrt_mid: the compiler's own algorithm minus the rescaling: s = v_sqrt_f32(x), then s - 1 ulp if x - (s - 1ulp) s <= 0,
 //             s + 1 ulp if x - (s + 1ulp) s > 0.  Checked exhaustively.
-__device__ __forceinline__ bool mid_range(float x) { const float a = fabsf(x); return a >= 0x1p-96f && a <= 0x1p+96f; }
-__device__ __forceinline__ bool div_range(float x) { const float a = fabsf(x); return a >= 0x1p-60f && a <= 0x1p+60f; }   // quotients and residuals stay normal
-__device__ __forceinline__ float rcp_mid(float x) {
-    float y = __builtin_amdgcn_rcpf(x);
-    float e = fmaf(-x, y, 1.0f);
-    y = fmaf(y, e, y);
-    e = fmaf(-x, y, 1.0f);
-    return fmaf(y, e, y);
-}
-__device__ __forceinline__ float div_mid(float a, float b, float rcp_b) {
-    const float q = a * rcp_b;
-    const float r = fmaf(-b, q, a);
-    return fmaf(r, rcp_b, q);
-}
-__device__ __forceinline__ float sqrt_mid(float x) {
-    const float s = __builtin_amdgcn_sqrtf(x);
-    const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
-    const float rm = fmaf(-sm, s, x), rp = fmaf(-sp, s, x);
-    float out = rm <= 0.0f ? sm : s;
-    out = rp > 0.0f ? sp : out;
-    return out;
-}
+// (mid_range, div_range, rcp_mid, div_mid, sqrt_mid: rt_math.h, where acos_s uses them too)
 __device__ __forceinline__ float rcp_ieee(float x) {          // == 1.0f / x
     if (mid_range(x)) return rcp_mid(x);
     return 1.0f / x;

@@ -83,6 +83,33 @@ RT_HD float cos_f(float x) { float s, c; sincos_f(x, &s, &c); return c; }
 // error of r = r1 - k*M is recovered exactly in `lo` (Fast2Sum when |r1| >= |k*M|, and when |r1| < |k*M| the subtraction
 // itself is exact); minimax kernels on |r| <= pi/4, sin(r) = r + r^3 P(r^2), cos(r) = 1 - r^2/2 + r^4 Q(r^2) with the
 // rounding error of 1 - r^2/2 carried along.
+#if defined(__HIPCC__)
+// The short exact forms of 1/x, a/b and sqrt(x) for mid-range operands (derivation and tests: rt_kernels.h, "IEEE f32 reciprocal,
+// division and square root"); device code only.
+__device__ __forceinline__ bool mid_range(float x) { const float a = fabsf(x); return a >= 0x1p-96f && a <= 0x1p+96f; }
+__device__ __forceinline__ bool div_range(float x) { const float a = fabsf(x); return a >= 0x1p-60f && a <= 0x1p+60f; }   // quotients and residuals stay normal
+__device__ __forceinline__ float rcp_mid(float x) {
+    float y = __builtin_amdgcn_rcpf(x);
+    float e = fmaf(-x, y, 1.0f);
+    y = fmaf(y, e, y);
+    e = fmaf(-x, y, 1.0f);
+    return fmaf(y, e, y);
+}
+__device__ __forceinline__ float div_mid(float a, float b, float rcp_b) {
+    const float q = a * rcp_b;
+    const float r = fmaf(-b, q, a);
+    return fmaf(r, rcp_b, q);
+}
+__device__ __forceinline__ float sqrt_mid(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rm = fmaf(-sm, s, x), rp = fmaf(-sp, s, x);
+    float out = rm <= 0.0f ? sm : s;
+    out = rp > 0.0f ? sp : out;
+    return out;
+}
+#endif
+
 #define RT_PIO2_H 1.57079637050628662109375f        // float(pi/2)
 #define RT_PIO2_M (-4.3711395392165286466e-08f)     // pi/2 - H rounded to 21 bits
 #define RT_PIO2_L 5.3903029534742383927e-15f        // pi/2 - H - M
@@ -115,13 +142,24 @@ RT_HD float acos_s(float u) {
     const float a = u < 0.0f ? -u : u;
     const bool small = a <= 0.5f;
     const float z = small ? u * u : (1.0f - a) * 0.5f;
+    // z is 0 or in [2^-46, 1/4], the divisor 2 sqrt(z) in [2^-22, 1], the residual 0 or in [2^-72, 2^-25]: always inside the range of the
+    // short exact forms, so the device takes them without a range check (same bits as sqrtf and `/`; acos_s is compared with the
+    // oracle's on every input the samplers can produce, tests/test_gpu_parity.py::test_device_math_bit_exact)
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float sq = sqrt_mid(z);
+#else
     const float sq = sqrtf(z);
+#endif
     float p = fmaf(0.04216630756855011f, z, 0.024179520085453987f);
     p = fmaf(p, z, 0.04547037556767464f);
     p = fmaf(p, z, 0.07495297491550446f);
     p = fmaf(p, z, 0.16666752099990845f);
     const float R = z * p;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float res = div_mid(fmaf(-sq, sq, z), sq + sq, rcp_mid(sq + sq));
+#else
     const float res = fmaf(-sq, sq, z) / (sq + sq);
+#endif
     const float c = sq > 0.0f ? res : 0.0f;
     const float w = fmaf(sq, R, c);
     const float r_small = RT_PIO2_H - (u - fmaf(-u, R, RT_PIO2_M));
