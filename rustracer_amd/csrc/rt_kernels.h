@@ -157,6 +157,7 @@ __device__ __forceinline__ vec3 screen_to_world(const rt_render_params& P, uint3
 //   sqrt_mid: the compiler's own algorithm minus the rescaling: s = v_sqrt_f32(x), then s - 1 ulp if x - (s - 1ulp) s <= 0,
 //             s + 1 ulp if x - (s + 1ulp) s > 0.  Checked exhaustively.
 // (mid_range, div_range, rcp_mid, div_mid, sqrt_mid: rt_math.h, where acos_s uses them too)
+__device__ __forceinline__ bool in_2pm20(float x) { const float a = fabsf(x); return a >= 0x1p-20f && a <= 0x1p+20f; }
 __device__ __forceinline__ float rcp_ieee(float x) {          // == 1.0f / x
     if (mid_range(x)) return rcp_mid(x);
     return 1.0f / x;
@@ -1172,10 +1173,28 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
           for (uint32_t ls = 0; ls < L; ++ls, ++j, row += 64) {                // for _ in 0..light_samples (raytracer.rs:269)
             const vec3 sp = add(xyz(cr), scale(random_sphere(&rng), cr.w));      // Sphere::random_point, objects.rs:223-226
             const vec3 ps = sub(sp, p);
-            const float d_s = sqrt_ieee(dot3(ps, ps));
-            const vec3 wi = scale(ps, rcp_ieee(d_s));                            // objects.rs:106-108; pdf and |wi.n| (objects.rs:109-115, raytracer.rs:278): k_shade_b, for the visible
+            // d_s = |ps|, wi = ps * (1 / d_s) (objects.rs:106-108), then the box ray of wi: direction normalised again, 1 / direction (mod.rs:506-512).
+            // One range test serves the whole chain: with every component of ps in [2^-20, 2^20], |ps|^2, |ps|, wi, |wi| ~ 1, wi / |wi| and its
+            // reciprocals all stay inside the ranges of the short exact forms (rt_math.h), which are then taken unguarded; any other sample point
+            // (a zero or tiny component: a ray along an axis) takes the guarded forms.  Same bits either way.
+            // pdf and |wi.n| (objects.rs:109-115, raytracer.rs:278): k_shade_b, for the visible samples only.
+            float d_s;
+            vec3 wi;
+            BoxRay br;
+            if (in_2pm20(ps.x) & in_2pm20(ps.y) & in_2pm20(ps.z)) {
+                d_s = sqrt_mid(dot3(ps, ps));
+                wi = scale(ps, rcp_mid(d_s));
+                const float n = sqrt_mid(dot3(wi, wi)), y = rcp_mid(n);
+                const vec3 u = mk(div_mid(wi.x, n, y), div_mid(wi.y, n, y), div_mid(wi.z, n, y));
+                br.ox = p.x; br.oy = p.y; br.oz = p.z;
+                br.ix = rcp_mid(u.x); br.iy = rcp_mid(u.y); br.iz = rcp_mid(u.z);
+                br.sx = u.x < 0.0f; br.sy = u.y < 0.0f; br.sz = u.z < 0.0f;
+            } else {
+                d_s = sqrt_ieee(dot3(ps, ps));
+                wi = scale(ps, rcp_ieee(d_s));
+                br = make_box_ray(p, wi);
+            }
             bool blocked = false;
-            const BoxRay br = make_box_ray(p, wi);
             const bool binary = !wide_ray_ok(br, p);
             if (!binary && (self_is_tri || self_is_sph) && slab_rel(br, own_dnx, own_dny, own_dnz, own_dxx, own_dxy, own_dxz)) {
                 float t = 0.0f;
