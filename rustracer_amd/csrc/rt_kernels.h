@@ -187,9 +187,17 @@ struct BoxRay {
     bool sx, sy, sz;
 };
 __device__ __forceinline__ BoxRay make_box_ray(vec3 o, vec3 d) {
-    const vec3 n = unit3_ieee(d);
     BoxRay r;
     r.ox = o.x; r.oy = o.y; r.oz = o.z;
+    if (in_2pm20(d.x) & in_2pm20(d.y) & in_2pm20(d.z)) {
+        // every component in [2^-20, 2^20]: |d|^2, |d|, d / |d| and its reciprocals stay inside the ranges of the short forms (one test, no nesting)
+        const float len = sqrt_mid(dot3(d, d)), y = rcp_mid(len);
+        const vec3 u = mk(div_mid(d.x, len, y), div_mid(d.y, len, y), div_mid(d.z, len, y));
+        r.ix = rcp_mid(u.x); r.iy = rcp_mid(u.y); r.iz = rcp_mid(u.z);
+        r.sx = u.x < 0.0f; r.sy = u.y < 0.0f; r.sz = u.z < 0.0f;
+        return r;
+    }
+    const vec3 n = unit3_ieee(d);
     if (mid_range(n.x) && mid_range(n.y) && mid_range(n.z)) {
         r.ix = rcp_mid(n.x); r.iy = rcp_mid(n.y); r.iz = rcp_mid(n.z);
     } else {
