@@ -305,7 +305,7 @@ def main():
         # the headline counts every Scene::intersect and Scene::is_occluded call, as SURVEY.md 8(d) defines a ray; most is_occluded calls are
         # settled by the test of the object the ray starts on and the per-light occluder cache, without a tree search.  This is the rate of
         # the rays that do search a tree (all intersect rays + the is_occluded rays k_trace_p traverses), world == 1 only.
-        "traversed_Mrays_per_s": (round((rays_closest + traced_shadow_per_step) * a.steps / elapsed / 1e6, 2) if traced_shadow_per_step is not None else None),
+        "traversed_Mrays_per_s": (round((rays_closest + traced_shadow_per_step) * a.steps / elapsed / 1e6, 2) if traced_shadow_per_step is not None and world == 1 else None),
         # HIP-event kernel times of the last timed step, summed per class; with more than one render lane kernels overlap and the sum exceeds the frame
         "kernel_ms_last_step": {"trace_shadow": round(cnt["kernel_ms_shadow"], 2), "trace_closest": round(cnt["kernel_ms_closest"], 2),
                                 "light_sampling": round(cnt["kernel_ms_light"], 2), "shade_generate_resolve": round(cnt["kernel_ms_shade"], 2)},
