@@ -168,7 +168,7 @@ int rt_get_counters(const rt_scene* scene, rt_counters* out);
  *   work to it), as long as each gets "lane_min_pixels" (65536) pixels; each lane has pass buffers of its own;
  *   "extend_persist" 0/1/2 Scene::intersect rays after the first bounce (2: camera rays too) go through the persistent
  *   k_extend_p, which refills finished lanes (default 1);
- *   "refill_min" (16), "phase_bias" (4), "shadow_waves" (8), "light_waves" (4), "inner_min" (12), "extend_refill" (24),
+ *   "refill_min" (16), "phase_bias" (16), "shadow_waves" (8), "light_waves" (4), "inner_min" (12), "extend_refill" (24),
  *   "extend_inner" (20), "extend_grid" (8 workgroups per CU): scheduling constants. */
 int rt_set_option(rt_scene* scene, const char* name, uint64_t value);
 /* The current value of an option of rt_set_option (no reference counterpart). */

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -133,7 +134,7 @@ struct rt_scene {
 
     DevBuf<float4> d_nodes, d_tris, d_tri_nrm, d_sph, d_mats, d_wnodes, d_wprims;
     DevBuf<uint2> d_sph_aux;
-    DevBuf<uint32_t> d_lights, d_ovf, d_wrec;
+    DevBuf<uint32_t> d_lights, d_ovf, d_wrec, d_wsib;
     HotTable hot_table;
     DevScene dev;
     uint64_t device_bytes = 0;
@@ -151,7 +152,7 @@ struct rt_scene {
 
     bool opt_stats = false, opt_timing = false;
     uint64_t opt_max_paths = 1ull << 24;
-    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 16, opt_phase_bias = 4, opt_shadow_waves = 8, opt_light_waves = 4, opt_hot = 1, opt_extend_persist = 1, opt_extend_refill = 24, opt_extend_inner = 20, opt_extend_grid = 8, opt_lanes = 3;
+    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 16, opt_phase_bias = 16, opt_shadow_waves = 8, opt_light_waves = 4, opt_hot = 1, opt_extend_persist = 1, opt_extend_refill = 24, opt_extend_inner = 20, opt_extend_grid = 8, opt_lanes = 3;
     uint64_t opt_lane_min_pixels = 65536;
     uint32_t grid_max = 2048;
 
@@ -168,6 +169,55 @@ uint32_t grid_for(const rt_scene* s, uint64_t n) {
     if (g < 1) g = 1;
     if (g > s->grid_max) g = s->grid_max;
     return (uint32_t)g;
+}
+
+// Per primitive record of the occlusion BVH: a coplanar neighbour for k_light's RT_LR_SKIP_SIB (rt_kernels.h).  A triangle whose three
+// vertices share one coordinate exactly has a flat box; among the other such triangles in the same plane (same axis, same coordinate) the
+// one whose box overlaps its box most is its neighbour: for a wall made of two triangles, the other half.  Word: bits 0..22 the
+// neighbour's record (RT_W_NO_REC: none), bits 23..24 the flat axis.  A choice of which record may be skipped on proof, nothing more.
+std::vector<uint32_t> coplanar_neighbours(const WideBVH& w) {
+    const uint32_t n = w.n_prims();
+    std::vector<uint32_t> out(n, RT_W_NO_REC);
+    struct Flat { uint32_t rec, axis; float lo[2], hi[2]; };
+    std::map<std::pair<uint32_t, uint32_t>, std::vector<Flat>> planes;   // (axis, bits of the coordinate; -0 counted as +0)
+    for (uint32_t r = 0; r < n; ++r) {
+        const float* p = &w.prims[12 * (size_t)r];
+        uint32_t kind;
+        memcpy(&kind, &p[3], 4);
+        if (kind != 0u) continue;   // a sphere
+        for (uint32_t a = 0; a < 3; ++a) {
+            if (!(p[a] == p[4 + a] && p[a] == p[8 + a])) continue;
+            Flat f;
+            f.rec = r; f.axis = a;
+            for (uint32_t k = 0; k < 2; ++k) {
+                const uint32_t b = (a + 1 + k) % 3;
+                f.lo[k] = std::min(p[b], std::min(p[4 + b], p[8 + b]));
+                f.hi[k] = std::max(p[b], std::max(p[4 + b], p[8 + b]));
+            }
+            const float c = p[a] + 0.0f;
+            uint32_t bits;
+            memcpy(&bits, &c, 4);
+            planes[std::make_pair(a, bits)].push_back(f);
+            break;
+        }
+    }
+    for (auto& kv : planes) {
+        std::vector<Flat>& g = kv.second;
+        for (size_t i = 0; i < g.size(); ++i) {
+            // the neighbours by record order are the neighbours in space (records follow the tree): look at 16 either side
+            double best = 0.0;
+            uint32_t pick = RT_W_NO_REC;
+            const size_t j0 = i > 16 ? i - 16 : 0, j1 = std::min(g.size(), i + 17);
+            for (size_t j = j0; j < j1; ++j) {
+                if (j == i) continue;
+                const double ox = (double)std::min(g[i].hi[0], g[j].hi[0]) - (double)std::max(g[i].lo[0], g[j].lo[0]);
+                const double oy = (double)std::min(g[i].hi[1], g[j].hi[1]) - (double)std::max(g[i].lo[1], g[j].lo[1]);
+                if (ox > 0.0 && oy > 0.0 && ox * oy > best) { best = ox * oy; pick = g[j].rec; }
+            }
+            out[g[i].rec] = pick | (g[i].axis << 23);
+        }
+    }
+    return out;
 }
 
 // Host half of Scene::new: the BVH and the light list (src/scene/mod.rs:91-99).  No GPU needed.
@@ -363,6 +413,9 @@ int upload_scene(rt_scene* s) {
         HIP_TRY(hipMemcpy(s->d_wprims.p, s->wide.prims.data(), s->wide.prims.size() * 4, hipMemcpyHostToDevice));
         if ((rc = s->d_wrec.ensure(s->wide.rec_of_obj.size()))) return rc;
         HIP_TRY(hipMemcpy(s->d_wrec.p, s->wide.rec_of_obj.data(), s->wide.rec_of_obj.size() * 4, hipMemcpyHostToDevice));
+        const std::vector<uint32_t> sib = coplanar_neighbours(s->wide);
+        if ((rc = s->d_wsib.ensure(sib.size() ? sib.size() : 1))) return rc;
+        if (!sib.empty()) HIP_TRY(hipMemcpy(s->d_wsib.p, sib.data(), sib.size() * 4, hipMemcpyHostToDevice));
     }
     if (ovf_rows && (rc = s->d_ovf.ensure((size_t)ovf_rows * s->grid_max * RT_BLOCK * RT_MAX_LANES))) return rc;   // one set of rows per render lane
     if (n_inner) {
@@ -398,7 +451,7 @@ int upload_scene(rt_scene* s) {
     }
     d.ovf = s->d_ovf.p; d.ovf_stride = s->grid_max * RT_BLOCK;
     d.inner_min = s->opt_inner_min; d.self_test = s->opt_self_test;
-    d.wnodes = s->d_wnodes.p; d.wprims = s->d_wprims.p; d.wrec = s->d_wrec.p;
+    d.wnodes = s->d_wnodes.p; d.wprims = s->d_wprims.p; d.wrec = s->d_wrec.p; d.wsib = s->d_wsib.p;
     {
         // Occluder cache of k_light: per light, up to RT_HOT non-emissive objects whose box overlaps the light's box (a light recessed
         // into or poking through a wall has most of its samples blocked by that wall) and that block enough rays to earn their test.
@@ -972,7 +1025,7 @@ void rt_scene_destroy(rt_scene* s) {
     (void)hipSetDevice(s->device);
     if (s->uploaded) (void)hipDeviceSynchronize();
     s->d_nodes.release(); s->d_tris.release(); s->d_tri_nrm.release(); s->d_sph.release(); s->d_mats.release();
-    s->d_sph_aux.release(); s->d_lights.release(); s->d_ovf.release(); s->d_wnodes.release(); s->d_wprims.release(); s->d_wrec.release();
+    s->d_sph_aux.release(); s->d_lights.release(); s->d_ovf.release(); s->d_wnodes.release(); s->d_wprims.release(); s->d_wrec.release(); s->d_wsib.release();
     for (int k = 0; k < RT_MAX_LANES; ++k) {
         s->ws[k].release();
         if (s->ws[k].stream) (void)hipStreamDestroy(s->ws[k].stream);

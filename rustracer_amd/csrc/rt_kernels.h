@@ -53,6 +53,7 @@ struct DevScene {
     const float4* wnodes;    // occlusion BVH (host_scene.h WideBVH): 5 x float4 per 8-wide node (80 B)
     const float4* wprims;    // 3 x float4 per blocker primitive record (48 B), in node order
     const uint32_t* wrec;    // primitive record of each object in wprims (0xFFFFFFFF: emissive, not in the tree)
+    const uint32_t* wsib;    // per primitive record: the record of a coplanar neighbour of an axis-flat triangle (bits 0..22, RT_W_NO_REC: none), its flat axis (bits 23..24)
     uint32_t n_wnodes;       // 0: shadow rays take the binary tree
     uint32_t refill_min;     // k_trace_p: idle lanes that trigger a refill of the wave
     uint32_t extend_refill_min;   // k_extend_p: the same for closest-hit rays
@@ -537,20 +538,23 @@ __device__ __forceinline__ uint32_t wide_child_mask(const BoxRay& br, float lim,
 // Group entries for the hit slots `hm` of a node (n0.w = meta, n1 = first inner child, first record): `a` primitives
 // (minus skip_rec, a record the caller has already tested for this ray, else RT_W_NO_REC), `b` inner nodes.
 #define RT_W_NO_REC 0x7FFFFFu
-__device__ __forceinline__ void wide_groups(uint32_t hm, uint32_t meta, uint32_t child_base, uint32_t prim_base, uint32_t skip_rec, uint32_t* a, uint32_t* b) {
+__device__ __forceinline__ void wide_groups(uint32_t hm, uint32_t meta, uint32_t child_base, uint32_t prim_base, uint32_t skip_rec, uint32_t skip_rec2,
+                                            uint32_t* a, uint32_t* b) {
     const uint32_t k = (meta >> 24) & 0xFu;
     const uint32_t ih = hm & ((1u << k) - 1u);
     uint32_t ph = hm >> k;
     // A ray that starts on a wall lies in the padded slab of that wall's own flat box, so the object a ray starts on is a
-    // candidate of nearly every such ray; k_light has tested it.
-    const uint32_t rel = skip_rec - prim_base;
+    // candidate of nearly every such ray; k_light has tested it.  skip_rec2: the wall's coplanar neighbour, when k_light has found
+    // that the ray cannot pass its box (RT_LR_SKIP_SIB).
+    const uint32_t rel = skip_rec - prim_base, rel2 = skip_rec2 - prim_base;
     if (rel < 8u) ph &= ~(1u << rel);
+    if (rel2 < 8u) ph &= ~(1u << rel2);
     *a = ph ? (RT_W_PRIM | (prim_base << 8) | ph) : 0u;
     *b = ih ? ((child_base << 8) | ih) : 0u;
 }
 
 template <bool STATS>
-__device__ __forceinline__ void wide_node_step(const DevScene& sc, const BoxRay& br, float lim, uint32_t skip_rec, uint32_t& cur, Stack& st, TravStats* ts) {
+__device__ __forceinline__ void wide_node_step(const DevScene& sc, const BoxRay& br, float lim, uint32_t skip_rec, uint32_t skip_rec2, uint32_t& cur, Stack& st, TravStats* ts) {
     const uint32_t node = (cur >> 8) + (uint32_t)__ffs((int)(cur & 0xFFu)) - 1u;
     uint32_t rest = cur & (cur - 1u);
     if (!(rest & 0xFFu)) rest = 0u;
@@ -559,7 +563,7 @@ __device__ __forceinline__ void wide_node_step(const DevScene& sc, const BoxRay&
     if (STATS) ts->wide++;
     const uint32_t hm = wide_child_mask(br, __float_as_uint(n1.z) ? __builtin_inff() : lim, n0, n2, n3, n4);   // n1.z: the node holds an ill-conditioned triangle (see prune_limit)
     uint32_t a, b;
-    wide_groups(hm, __float_as_uint(n0.w), __float_as_uint(n1.x), __float_as_uint(n1.y), skip_rec, &a, &b);   // primitives first: a blocker ends the ray
+    wide_groups(hm, __float_as_uint(n0.w), __float_as_uint(n1.x), __float_as_uint(n1.y), skip_rec, skip_rec2, &a, &b);   // primitives first: a blocker ends the ray
     uint32_t c = rest;
     if (!a) { a = b; b = 0u; }
     if (!a) { a = c; c = 0u; }
@@ -622,7 +626,7 @@ __device__ __forceinline__ bool occluded(const DevScene& sc, bool have_ray, vec3
             const unsigned long long mi = __ballot(at_inner);
             if (!mi) break;
             if ((uint32_t)__popcll(mi) < inner_min && __ballot((cur & RT_W_PRIM) != 0u) != 0ull) break;
-            if (at_inner) wide_node_step<STATS>(sc, br, lim, RT_W_NO_REC, cur, st, ts);
+            if (at_inner) wide_node_step<STATS>(sc, br, lim, RT_W_NO_REC, RT_W_NO_REC, cur, st, ts);
         }
         if (cur & RT_W_PRIM)
             if (wide_prim_step<STATS>(sc, br, o, d, max_dist, cur, st, ts)) occ = true;
@@ -1112,6 +1116,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SHADOW_WAVES) k_shadow(DevScene s
 // What the reference computes for a visible sample only (pdf, |wi.n|) is left to k_shade_b.
 #define RT_LR_BLOCKED 0x80000000u   // sign bit of the ray's distance in pc.lray, set by k_trace_p / k_binary: the ray is occluded (a distance is never negative)
 #define RT_LR_LANE_SHIFT 23         // bits 23..28: the ray's vertex within its tile of 64 (bits 0..22: the record of the object it starts on)
+#define RT_LR_SKIP_SIB 0x20000000u  // the coplanar neighbour of the triangle the ray starts on (sc.wsib) cannot be a candidate: k_trace_p skips its record too
 #define RT_LR_BINARY 0x40000000u    // the ray has a non-finite or huge 1/d: k_binary settles it on the binary tree, k_trace_p drops it
 __device__ __forceinline__ size_t ls_slot(uint32_t e, uint32_t j, uint32_t nlL) {
     return (size_t)(e >> 6) * (64u * (size_t)nlL) + (size_t)j * 64u + (e & 63u);
@@ -1146,6 +1151,19 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
         }
         // its record in the occlusion BVH: k_trace_p need not test it again for the rays that pass the test here
         const uint32_t self_rec = (self_is_tri || self_is_sph) ? sc.wrec[self_obj] : RT_W_NO_REC;
+        // A wall is two coplanar triangles with the same flat box: a ray that starts on one lies in the padded slab of the other's box and
+        // would take its primitive test in k_trace_p, nearly always for nothing.  The reference tests that neighbour only if the ray passes
+        // its own box (bvh slab test); on the flat axis both planes are the coordinate c, so the test ends with ray_max <= (c - o) * (1/d)
+        // and fails whenever that product is not positive.  (c - o) is a vertex value; the product and its sign are the slab test's own.
+        uint32_t sib_axis = 0u;
+        float sib_d = 0.0f;
+        bool has_sib = false;
+        if (self_is_tri && self_rec != RT_W_NO_REC) {
+            const uint32_t w = sc.wsib[self_rec];
+            has_sib = (w & RT_W_NO_REC) != RT_W_NO_REC;
+            sib_axis = w >> 23;
+            sib_d = (sib_axis == 0u ? A.x : (sib_axis == 1u ? A.y : A.z)) - (sib_axis == 0u ? p.x : (sib_axis == 1u ? p.y : p.z));
+        }
         // its own box (Bounded, objects.rs:293-316), relative to the vertex: one slab test serves the triangle and the sphere lanes of a wave
         const float own_dnx = (self_is_sph ? A.x - A.w : lo3(A.x, B.x, C.x)) - p.x, own_dny = (self_is_sph ? A.y - A.w : lo3(A.y, B.y, C.y)) - p.y,
                     own_dnz = (self_is_sph ? A.z - A.w : lo3(A.z, B.z, C.z)) - p.z;
@@ -1241,7 +1259,10 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
             if (keep) {
                 const size_t at = row + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                 pc.lray[at] = make_float4(wi.x, wi.y, wi.z, d_s);
-                pc.linv[at] = make_float4(br.ix, br.iy, br.iz, __uint_as_float(self_rec | (__lane_id() << RT_LR_LANE_SHIFT) | (binary ? RT_LR_BINARY : 0u)));
+                const float sib_i = sib_axis == 0u ? br.ix : (sib_axis == 1u ? br.iy : br.iz);
+                const bool skip_sib = has_sib && !(sib_d * sib_i > 0.0f);
+                pc.linv[at] = make_float4(br.ix, br.iy, br.iz, __uint_as_float(self_rec | (__lane_id() << RT_LR_LANE_SHIFT) | (binary ? RT_LR_BINARY : 0u) |
+                                                                               (skip_sib ? RT_LR_SKIP_SIB : 0u)));
                 if (binary) pc.blist[atomicAdd(&pc.bcounts[level], 1u)] = (uint32_t)at;
             }
             if (__lane_id() == 0u) row_mask[j] = m;
@@ -1307,7 +1328,7 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
     uint32_t w_steps[6] = {0, 0, 0, 0, 0, 0};   // STATS: wave steps and the lanes that took part (node, primitive, refill)
 
     // the ray this lane is tracing (cur != 0)
-    uint32_t cur = 0u, slot = 0u, rec_word = 0u, skip_rec = RT_W_NO_REC;
+    uint32_t cur = 0u, slot = 0u, rec_word = 0u, skip_rec = RT_W_NO_REC, skip_rec2 = RT_W_NO_REC;
     vec3 o = mk(0.0f, 0.0f, 0.0f), d = mk(0.0f, 0.0f, 1.0f);
     BoxRay br = make_box_ray(o, d);
     float max_dist = 0.0f, lim = 0.0f;
@@ -1356,6 +1377,7 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
                 br.ox = o.x; br.oy = o.y; br.oz = o.z;
                 br.ix = I4.x; br.iy = I4.y; br.iz = I4.z;                     // make_box_ray(o, d), computed by k_light
                 skip_rec = rec_word & RT_W_NO_REC;                             // the object the ray starts on: tested by k_light
+                skip_rec2 = (rec_word & RT_LR_SKIP_SIB) ? (sc.wsib[skip_rec] & RT_W_NO_REC) : RT_W_NO_REC;
                 br.sx = I4.x < 0.0f; br.sy = I4.y < 0.0f; br.sz = I4.z < 0.0f; // sign of the normalised direction (finite 1/d only: wide_ray_ok)
                 lim = prune_limit(max_dist);
                 st.sp = 0;
@@ -1370,7 +1392,7 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
         const uint32_t n_node = (uint32_t)__popcll(__ballot(at_node)), n_prim = (uint32_t)__popcll(__ballot(at_prim));
         if (n_node != 0u && (n_prim == 0u || 4u * n_node >= phase_bias * n_prim)) {
             if (STATS) { w_steps[0]++; w_steps[1] += n_node; }
-            if (at_node) wide_node_step<STATS>(sc, br, lim, skip_rec, cur, st, &tst);
+            if (at_node) wide_node_step<STATS>(sc, br, lim, skip_rec, skip_rec2, cur, st, &tst);
         } else {
             if (STATS) { w_steps[2]++; w_steps[3] += n_prim; }
             if (at_prim && wide_prim_step<STATS>(sc, br, o, d, max_dist, cur, st, &tst)) words[4 * (size_t)slot + 3] = __float_as_uint(max_dist) | RT_LR_BLOCKED;

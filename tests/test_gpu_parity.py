@@ -268,7 +268,7 @@ def test_occluder_cache_and_scheduling_switches_do_not_change_a_pixel(gpu):
     osc, gsc = _two_light_scene()
     ref = osc.render(op)
     p = to_rt_params(op)
-    for opts in ({}, {"self_test": 0}, {"refill_min": 1, "phase_bias": 1}, {"refill_min": 64, "phase_bias": 16, "shadow_waves": 5},
+    for opts in ({}, {"self_test": 0}, {"refill_min": 1, "phase_bias": 1}, {"refill_min": 64, "phase_bias": 4, "shadow_waves": 5},
                  {"light_waves": 8}, {"extend_persist": 0}, {"extend_persist": 2, "extend_refill": 1, "extend_inner": 1},
                  {"extend_persist": 2, "extend_refill": 64, "extend_inner": 64, "extend_grid": 1}, {"extend_refill": 7, "extend_inner": 40, "extend_grid": 3}):
         for k, v in opts.items():
@@ -276,7 +276,7 @@ def test_occluder_cache_and_scheduling_switches_do_not_change_a_pixel(gpu):
         got, cnt = gpu_render(gsc, p)
         assert np.array_equal(got, ref["rgba"]), opts
         assert cnt["rays_shadow"] == ref["occluded_calls"] and cnt["rays_closest"] == ref["intersect_calls"], opts
-        for k, v in {"self_test": 1, "refill_min": 16, "phase_bias": 4, "shadow_waves": 8, "light_waves": 4, "extend_persist": 1, "extend_refill": 24,
+        for k, v in {"self_test": 1, "refill_min": 16, "phase_bias": 16, "shadow_waves": 8, "light_waves": 4, "extend_persist": 1, "extend_refill": 24,
                      "extend_inner": 20, "extend_grid": 8}.items():
             gsc.set_option(k, v)
     with pytest.raises(Exception):
@@ -315,6 +315,53 @@ def test_render_lanes_do_not_change_a_pixel(scenes):
         gsc.set_option("lanes", 3)
         gsc.set_option("max_paths", 0)
         gsc.set_option("lane_min_pixels", 65536)
+
+
+def test_coplanar_neighbours_of_a_tessellated_wall(gpu):
+    """k_light flags a ray whose start triangle has a coplanar neighbour the ray provably cannot pass (the flat axis of the bvh slab test ends
+    with ray_max <= (c - o) / d <= 0), and k_trace_p then skips that neighbour's record as it skips the start triangle's.  Held against the
+    oracle where neighbours abound: a room whose floor, ceiling and back wall are grids of coplanar triangles (each triangle has several
+    neighbours in its plane, only one of which may be skipped), with a lamp and a blocker box; image and ray counts identical, and the
+    counters show the skip at work (far fewer primitive tests than traced rays)."""
+    from oracle import binding as ob
+    import rustracer_amd as ra
+    tris = []
+
+    def grid(axis, c, n, lo=-5.0, hi=5.0, flip=False):
+        xs = np.linspace(lo, hi, n + 1, dtype=np.float32)
+        o = [(axis + 1) % 3, (axis + 2) % 3]
+        for i in range(n):
+            for j in range(n):
+                q = []
+                for (u, v) in ((xs[i], xs[j]), (xs[i + 1], xs[j]), (xs[i + 1], xs[j + 1]), (xs[i], xs[j + 1])):
+                    pt = [0.0, 0.0, 0.0]
+                    pt[axis], pt[o[0]], pt[o[1]] = c, u, v
+                    q.append(pt)
+                a, b, cc, d = q
+                tris.append(a + b + cc if not flip else a + cc + b)
+                tris.append(a + cc + d if not flip else a + d + cc)
+    grid(1, -5.0, 5)            # floor y = -5
+    grid(1, 5.0, 4, flip=True)  # ceiling y = 5
+    grid(2, -15.0, 3)           # back wall z = -15 (x, y in [-5, 5])
+    tri = np.array(tris, np.float32)
+    tri[:, [2, 5, 8]] += np.where(np.isin(np.arange(tri.shape[0]), np.arange(0, 82)), -10.0, 0.0).astype(np.float32)[:, None]   # floor and ceiling in front of the camera
+    blocker = np.array([[-1, -5, -9, 1, -5, -9, 0, -2, -10], [-1, -5, -11, 0, -2, -10, 1, -5, -11]], np.float32)
+    tri = np.concatenate([tri, blocker])
+    nrm = np.tile(np.array([0, 1, 0, 0, 1, 0, 0, 1, 0], np.float32), (tri.shape[0], 1))
+    mats = np.zeros((2, 8), np.uint32)
+    mats[0, 1:4] = np.float32(0.6).view(np.uint32)
+    mats[1, 4:7] = np.float32(40.0).view(np.uint32)
+    sph = np.array([[0.0, 4.6, -10.0, 0.8]], np.float32)       # lamp poking through the ceiling grid
+    args = (tri, nrm, np.zeros(tri.shape[0], np.uint32), sph, np.array([1], np.uint32), mats)
+    osc, gsc = ob.OracleScene.raw(*args), ra.Scene.from_arrays(*args)
+    op = oracle_params(width=96, height=80, spp=4, light_samples=8, bounces=3, seed=31)
+    ref = osc.render(op)
+    gsc.set_option("stats", 1)
+    got, cnt = gpu_render(gsc, to_rt_params(op))
+    assert np.array_equal(got, ref["rgba"]), "%d bytes differ" % int((got != ref["rgba"]).sum())
+    assert cnt["rays_closest"] == ref["intersect_calls"] and cnt["rays_shadow"] == ref["occluded_calls"]
+    steps = cnt["trace_steps"]
+    assert steps[5] > 1000 and steps[3] < steps[5]      # primitive tests (lanes of prim steps) < rays handed to k_trace_p
 
 
 def test_occluder_cache_with_a_sphere_next_to_the_lamp(gpu):
