@@ -133,13 +133,20 @@ def lib():
 
 
 def kernel_source_hash():
-    """sha256 over the sources the device code is built from: stamps profiles (tools/profile.sh) so that bench.py can tell whether
-    committed PMC figures were measured on the kernels it is running."""
+    """sha256 over the sources the device code is built from, comments and white space left out: stamps profiles (tools/profile.sh) so
+    that bench.py can tell whether committed PMC figures were measured on the kernels it is running."""
     import hashlib
+    import re
     h = hashlib.sha256()
     for name in ("rt_kernels.h", "rt_math.h", "rt_api.hip", "host_scene.h", "Makefile"):
-        with open(os.path.join(_HERE, "csrc", name), "rb") as f:
-            h.update(f.read())
+        with open(os.path.join(_HERE, "csrc", name), "r", errors="replace") as f:
+            text = f.read()
+        if name != "Makefile":
+            text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)      # block comments
+            text = re.sub(r"//[^\n]*", " ", text)                   # line comments (no string literal in these sources holds "//")
+        else:
+            text = re.sub(r"#[^\n]*", " ", text)
+        h.update(" ".join(text.split()).encode())
     return h.hexdigest()[:16]
 
 

@@ -2,13 +2,19 @@
 //
 // One pass renders `npaths` camera samples in lock step.  Per bounce level k (bounces_left =
 // bounces - k, src/raytracer.rs:330-350) the host enqueues
-//   k_extend   closest-hit BVH traversal over the live ray queue      (Scene::intersect, mod.rs:406-447)
+//   k_extend / k_extend_p  closest-hit BVH traversal over the live ray queue (Scene::intersect, mod.rs:406-447): camera rays / the
+//              rays after the first bounce, the latter in persistent waves that hand new rays to finished lanes
 //   k_shade_a  hit point + shading normal, terminates misses / depth 0 (mod.rs:58-67, raytracer.rs:339)
-//   k_shadow   one thread per (vertex, light, light sample): sample_l + any-hit traversal + ordered
-//              in-wave sum of the vertex's samples                     (objects.rs:96-118, mod.rs:452-491)
-//   k_shade_b  ordered sum of the light samples, emission, Russian roulette, BSDF sample, and
+//   k_light    one thread per vertex over its lights x light samples: Object::sample_l's point and ray (objects.rs:96-108) and the
+//              is_occluded tests that need no traversal (the object the ray starts on, the light's occluder cache); the rays it
+//              cannot settle are packed at the front of their row of 64
+//   k_binary   those of them with a non-finite 1/d, on the binary tree     (mod.rs:452-491)
+//   k_trace_p  the others, on the 8-wide occlusion BVH, in persistent waves with lane refill
+//   k_shade_b  pdf, cosine and the ordered sum of the visible light samples, emission, Russian roulette, BSDF sample, and
 //              wave64 ballot compaction of the surviving paths into the next ray queue
-//                                                                      (raytracer.rs:251-326)
+//                                                                      (objects.rs:109-115, raytracer.rs:251-326)
+//   (k_shadow  one thread per (vertex, light sample), sampling and traversal in one kernel: the hemisphere estimator, and the
+//              importance estimator when the occlusion BVH is switched off)
 // and finally k_resolve adds the finished samples to their pixels in sample order
 // (raytracer.rs:236-239) and tone-maps (common.rs:46-58, raytracer.rs:43-51).
 //
