@@ -141,6 +141,11 @@
 #define I_CMPU(i) asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(u##i), "v"(u0) : "vcc");
 #define I_ADDF16(i) asm volatile("v_pk_add_f16 %0, %0, %1" : "+v"(u##i) : "v"(u0));
 
+#define I_FMAMIX(i) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(a##i) : "v"(u##i), "v"(c1));
+#define I_FMAMIXHI(i) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a##i) : "v"(u##i), "v"(c1));
+#define I_P_FMAMIX_MAX3(i) asm volatile("v_fma_mix_f32 %0, %4, %2, %0 op_sel_hi:[1,0,0]\n v_max3_f32 %1, %1, %2, %3" : "+v"(a##i), "+v"(b##i) : "v"(c1), "v"(c2), "v"(u##i));
+#define I_CVTF16(i) asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(a##i) : "v"(u##i));
+
 KERNEL(k_fma32, I_FMA32) KERNEL(k_mul32, I_MUL32) KERNEL(k_add32, I_ADD32) KERNEL(k_fma64, I_FMA64) KERNEL(k_mul64, I_MUL64) KERNEL(k_add64, I_ADD64)
 KERNEL(k_rcp32, I_RCP32) KERNEL(k_sqrt32, I_SQRT32) KERNEL(k_rsq32, I_RSQ32) KERNEL(k_mullo, I_MULLO) KERNEL(k_mulhi, I_MULHI) KERNEL(k_mad64, I_MAD64)
 KERNEL(k_mul24, I_MUL24) KERNEL(k_addu, I_ADDU) KERNEL(k_lshl, I_LSHL) KERNEL(k_cvtub, I_CVTUB) KERNEL(k_max3, I_MAX3) KERNEL(k_cndmask, I_CNDMASK)
@@ -148,7 +153,7 @@ KERNEL(k_cmp, I_CMP) KERNEL(k_ldexp, I_LDEXP) KERNEL(k_pkfma, I_PKFMA) KERNEL(k_
 KERNEL(k_divfixup, I_DIVFIXUP) KERNEL(k_rcp64, I_RCP64) KERNEL(k_mov, I_MOV) KERNEL(k_bfe, I_BFE) KERNEL(k_mbcnt, I_MBCNT)
 KERNEL(k_fma32_salu, I_FMA32_SALU) KERNEL(k_fma32_2salu, I_FMA32_2SALU)
 
-KERNEL(kx0, I_SUB32) KERNEL(kx1, I_MAX32) KERNEL(kx2, I_MIN32) KERNEL(kx3, I_MIN3) KERNEL(kx4, I_MED3) KERNEL(kx5, I_FMAC) KERNEL(kx6, I_FMAAK) KERNEL(kx7, I_MULS) KERNEL(kx8, I_MULABS) KERNEL(kx9, I_AND) KERNEL(kx10, I_OR) KERNEL(kx11, I_XOR) KERNEL(kx12, I_LSHR) KERNEL(kx13, I_SUBU) KERNEL(kx14, I_ADDCO) KERNEL(kx15, I_ADD3) KERNEL(kx16, I_LSHLADD) KERNEL(kx17, I_LSHLOR) KERNEL(kx18, I_ANDOR) KERNEL(kx19, I_BFI) KERNEL(kx20, I_PERM) KERNEL(kx21, I_ALIGNBIT) KERNEL(kx22, I_CVTU) KERNEL(kx23, I_CVTUB0) KERNEL(kx24, I_CVTF2U) KERNEL(kx25, I_RNDNE) KERNEL(kx26, I_CMPCND) KERNEL(kx27, I_CMPS) KERNEL(kx28, I_CMPCNDS) KERNEL(kx29, I_CNDS) KERNEL(kx30, I_CMPX) KERNEL(kx31, I_RDFL) KERNEL(kx32, I_DPP) KERNEL(kx33, I_BPERM) KERNEL(kx34, I_P_FMA_MAX3) KERNEL(kx35, I_P_FMA_CVT) KERNEL(kx36, I_P_MUL_ADD) KERNEL(kx37, I_P_MAX3_CVT) KERNEL(kx38, I_P_FMA_RCP) KERNEL(kx39, I_P_MAX3_RCP) KERNEL(kx40, I_P_FMA_FMA64) KERNEL(kx41, I_P_FMA_AND) KERNEL(kx42, I_T_FMA_FMA_MAX3) KERNEL(ky0, I_FMAS) KERNEL(ky1, I_FMASS) KERNEL(ky2, I_ADDS) KERNEL(ky3, I_SUBS) KERNEL(ky4, I_ANDS) KERNEL(ky5, I_ADDUS) KERNEL(ky6, I_MOVS) KERNEL(ky7, I_MULC) KERNEL(ky8, I_MULL) KERNEL(ky9, I_ADDC) KERNEL(ky10, I_FMAC2) KERNEL(ky11, I_MAXS) KERNEL(ky12, I_LSHLV) KERNEL(ky13, I_LSHRV) KERNEL(ky14, I_ASHR) KERNEL(ky15, I_NOT) KERNEL(ky16, I_BCNT) KERNEL(ky17, I_FFBL) KERNEL(ky18, I_MINU) KERNEL(ky19, I_CMPU) KERNEL(ky20, I_ADDF16) 
+KERNEL(kx0, I_SUB32) KERNEL(kx1, I_MAX32) KERNEL(kx2, I_MIN32) KERNEL(kx3, I_MIN3) KERNEL(kx4, I_MED3) KERNEL(kx5, I_FMAC) KERNEL(kx6, I_FMAAK) KERNEL(kx7, I_MULS) KERNEL(kx8, I_MULABS) KERNEL(kx9, I_AND) KERNEL(kx10, I_OR) KERNEL(kx11, I_XOR) KERNEL(kx12, I_LSHR) KERNEL(kx13, I_SUBU) KERNEL(kx14, I_ADDCO) KERNEL(kx15, I_ADD3) KERNEL(kx16, I_LSHLADD) KERNEL(kx17, I_LSHLOR) KERNEL(kx18, I_ANDOR) KERNEL(kx19, I_BFI) KERNEL(kx20, I_PERM) KERNEL(kx21, I_ALIGNBIT) KERNEL(kx22, I_CVTU) KERNEL(kx23, I_CVTUB0) KERNEL(kx24, I_CVTF2U) KERNEL(kx25, I_RNDNE) KERNEL(kx26, I_CMPCND) KERNEL(kx27, I_CMPS) KERNEL(kx28, I_CMPCNDS) KERNEL(kx29, I_CNDS) KERNEL(kx30, I_CMPX) KERNEL(kx31, I_RDFL) KERNEL(kx32, I_DPP) KERNEL(kx33, I_BPERM) KERNEL(kx34, I_P_FMA_MAX3) KERNEL(kx35, I_P_FMA_CVT) KERNEL(kx36, I_P_MUL_ADD) KERNEL(kx37, I_P_MAX3_CVT) KERNEL(kx38, I_P_FMA_RCP) KERNEL(kx39, I_P_MAX3_RCP) KERNEL(kx40, I_P_FMA_FMA64) KERNEL(kx41, I_P_FMA_AND) KERNEL(kx42, I_T_FMA_FMA_MAX3) KERNEL(ky0, I_FMAS) KERNEL(ky1, I_FMASS) KERNEL(ky2, I_ADDS) KERNEL(ky3, I_SUBS) KERNEL(ky4, I_ANDS) KERNEL(ky5, I_ADDUS) KERNEL(ky6, I_MOVS) KERNEL(ky7, I_MULC) KERNEL(ky8, I_MULL) KERNEL(ky9, I_ADDC) KERNEL(ky10, I_FMAC2) KERNEL(ky11, I_MAXS) KERNEL(ky12, I_LSHLV) KERNEL(ky13, I_LSHRV) KERNEL(ky14, I_ASHR) KERNEL(ky15, I_NOT) KERNEL(ky16, I_BCNT) KERNEL(ky17, I_FFBL) KERNEL(ky18, I_MINU) KERNEL(ky19, I_CMPU) KERNEL(ky20, I_ADDF16) KERNEL(kz0, I_FMAMIX) KERNEL(kz1, I_FMAMIXHI) KERNEL(kz2, I_P_FMAMIX_MAX3) KERNEL(kz3, I_CVTF16)
 typedef void (*kern_t)(float*, unsigned long long*, int, int, float);
 struct Entry { const char* name; kern_t k; int per; };
 
@@ -181,6 +186,10 @@ int main(int argc, char** argv) {
         {"v_min_u32", ky18, 1},
         {"v_cmp_lt_u32", ky19, 1},
         {"v_pk_add_f16", ky20, 1},
+        {"v_fma_mix_f32 (f16 lo, f32, f32)", kz0, 1},
+        {"v_fma_mix_f32 (f16 hi, f32, f32)", kz1, 1},
+        {"PAIR fma_mix | max3", kz2, 2},
+        {"v_cvt_f32_f16", kz3, 1},
         {"v_sub_f32", kx0, 1},
         {"v_max_f32", kx1, 1},
         {"v_min_f32", kx2, 1},
