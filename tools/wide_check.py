@@ -1,4 +1,5 @@
-"""One-off wide parity check of BASELINE config 4 at its full spp: GPU frame against the oracle on every K-th 32x32 tile, shard offset J."""
+"""One-off wide parity check of BASELINE config 4 (or 5: third argument) at its full spp: GPU frame against the oracle on every K-th 32x32
+tile, shard offset J."""
 import sys, time
 import numpy as np
 sys.path.insert(0, ".")
@@ -8,11 +9,17 @@ from oracle import binding as ob
 from test_gpu_parity import oracle_params, to_rt_params, gpu_render, _own_tiles
 
 J, K = int(sys.argv[1]), int(sys.argv[2])
+CONFIG = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 ra._lib.check(ra._lib.lib().rt_init(0))
-vp, vn, f = ra.dragon_standin_mesh(*ra.DRAGON_STANDIN_FULL)
-osc, gsc = ob.OracleScene.dragon_mesh(vp, vn, f), ra.Scene.from_dragon_mesh(vp, vn, f)
-W, H = 1920, 1080
-op = oracle_params(width=W, height=H, spp=256, light_samples=32, bounces=8, seed=0x5EED, tile=(32, 32), shard=(J, K))
+if CONFIG == 4:
+    vp, vn, f = ra.dragon_standin_mesh(*ra.DRAGON_STANDIN_FULL)
+    osc, gsc = ob.OracleScene.dragon_mesh(vp, vn, f), ra.Scene.from_dragon_mesh(vp, vn, f)
+    W, H, SPP = 1920, 1080, 256
+else:       # config 5: new_specular's spheres + the teapot, 3840x2160, 1024 spp
+    from conftest import TEAPOT_OBJ as teapot
+    osc, gsc = ob.OracleScene.named("specular_teapot", teapot), ra.Scene._named("specular_teapot", teapot)
+    W, H, SPP = 3840, 2160, 1024
+op = oracle_params(width=W, height=H, spp=SPP, light_samples=32, bounces=8, seed=0x5EED, tile=(32, 32), shard=(J, K))
 t0 = time.time(); ref = osc.render(op); t1 = time.time()
 gsc.set_option("lane_min_pixels", 64)
 got, cnt = gpu_render(gsc, to_rt_params(op)); t2 = time.time()
