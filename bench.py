@@ -211,6 +211,11 @@ def main():
                 "what": "Object::sample_l for every (vertex, light sample) + the test of the object the ray starts on + the per-light occluder cache",
                 "unit": "light sample", "bytes_per_unit": round(b_light, 2), "units_per_launch": round(cnt["rays_shadow"] / launches, 1),
                 "launches_per_step": int(launches), "ms_per_step": round(cnt["kernel_ms_light"], 2)}
+            sh = sc["shaft"]
+            if sh[0]:
+                # the per-(vertex, light) beam walk: how many beams were walked, how many were clear, what the walk cost
+                kernels["k_light"]["shaft"] = {"beams_walked_per_vertex_light": round(sh[0] * a.light_samples / n_shadow, 4), "clear_fraction_of_walked": round(sh[1] / sh[0], 4),
+                                               "nodes_per_walk": round(sh[2] / sh[0], 3), "rays_settled_visible_fraction_of_is_occluded_rays": round(sh[3] / n_shadow, 4)}
         else:
             # binary-tree kernel (option wide=0 / persist=0, or a scene outside the 8-wide tree's range): SURVEY.md §8(d) formula
             b_shadow = (80.0 * sc["shadow_wide"] + 64.0 * sc["shadow_inner"] + 48.0 * sc["shadow_tris"] + 16.0 * sc["shadow_sphs"]) / n_shadow + 48.0

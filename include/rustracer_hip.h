@@ -80,6 +80,8 @@ typedef struct rt_counters {
     double   kernel_ms_light; /* HIP-event time of k_light alone (Object::sample_l, own-object test, occluder cache), timing enabled */
     uint64_t trace_steps[8];  /* persistent traversal kernel, "stats" on: wave-wide node steps, lanes in them, primitive steps, lanes, refills, lanes,
                                * primitive records whose own box the ray misses (false candidates of the quantised tree), spare */
+    uint64_t shaft[4];        /* per-(vertex, light) beam test of k_light ("shaft" option), "stats" on: beams walked, beams found clear, nodes
+                               * visited by the walks, light-sample rays settled as visible without a traversal */
 } rt_counters;
 
 typedef struct rt_scene rt_scene;
@@ -168,6 +170,9 @@ int rt_get_counters(const rt_scene* scene, rt_counters* out);
  *   work to it), as long as each gets "lane_min_pixels" (65536) pixels; each lane has pass buffers of its own;
  *   "extend_persist" 0/1/2 Scene::intersect rays after the first bounce (2: camera rays too) go through the persistent
  *   k_extend_p, which refills finished lanes (default 1);
+ *   "shaft" 0..16 (default 8): k_light walks the occlusion BVH once per (vertex, light) with the convex hull of the vertex and
+ *   the light's box, visiting at most that many nodes; a beam that can meet no primitive record settles its unblocked rays as visible
+ *   and they skip k_trace_p (0 = off);
  *   "refill_min" (16), "phase_bias" (16), "shadow_waves" (8), "light_waves" (4), "inner_min" (12), "extend_refill" (24),
  *   "extend_inner" (20), "extend_grid" (8 workgroups per CU): scheduling constants. */
 int rt_set_option(rt_scene* scene, const char* name, uint64_t value);

@@ -99,6 +99,7 @@ pub struct rt_counters {
     pub shadow_wide: u64,
     pub kernel_ms_light: f64,
     pub trace_steps: [u64; 8],
+    pub shaft: [u64; 4],
 }
 
 /// Opaque scene handle (`Scene`, src/scene/mod.rs:19-24, plus its device copy).
@@ -170,6 +171,6 @@ mod layout {
         assert_eq!(size_of::<rt_material>(), 32);
         assert_eq!(size_of::<rt_render_params>(), 88);
         assert_eq!(size_of::<rt_scene_info>(), 48);
-        assert_eq!(size_of::<rt_counters>(), 208);
+        assert_eq!(size_of::<rt_counters>(), 240);
     }
 }

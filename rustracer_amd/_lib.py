@@ -55,10 +55,10 @@ class Counters(C.Structure):
                 ("shadow_inner", C.c_uint64), ("shadow_tris", C.c_uint64), ("shadow_sphs", C.c_uint64),
                 ("closest_hits_tri", C.c_uint64), ("closest_hits_sph", C.c_uint64),
                 ("kernel_ms_closest", C.c_double), ("kernel_ms_shadow", C.c_double), ("kernel_ms_shade", C.c_double),
-                ("launches_closest", C.c_uint64), ("launches_shadow", C.c_uint64), ("shadow_wide", C.c_uint64), ("kernel_ms_light", C.c_double), ("trace_steps", C.c_uint64 * 8)]
+                ("launches_closest", C.c_uint64), ("launches_shadow", C.c_uint64), ("shadow_wide", C.c_uint64), ("kernel_ms_light", C.c_double), ("trace_steps", C.c_uint64 * 8), ("shaft", C.c_uint64 * 4)]
 
     def as_dict(self):
-        return {n: (list(getattr(self, n)) if n == "trace_steps" else getattr(self, n)) for n, _ in self._fields_}
+        return {n: (list(getattr(self, n)) if n in ("trace_steps", "shaft") else getattr(self, n)) for n, _ in self._fields_}
 
 
 # every symbol include/rustracer_hip.h declares

@@ -53,6 +53,7 @@ int fail(int code, const std::string& msg) {
 #define RT_NOALLOC_BYTES (256u + RT_NOALLOC_ROWS * RT_NOALLOC_GRID * RT_BLOCK * 4u)   // 16 MiB + 256 B
 #define RT_MAX_DEVICES 64
 static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_BYTES];
+static_assert(ST_COUNT * sizeof(unsigned long long) <= 256, "the counters must fit the first 256 bytes of the scratch");
 void* g_scratch_ptr[RT_MAX_DEVICES];   // device address of `scratch` on each GPU this process has asked for (nullptr: not yet)
 
 // Device address of this GPU's copy of `scratch`; `device` must be the current device.
@@ -97,14 +98,14 @@ struct Workspace {
     DevBuf<float> hit_t;
     DevBuf<float4> ray_o[2], ray_d[2], vP, vN, vS, contrib, direct, stackA, stackB, radiance, lray, linv;
     DevBuf<uint64_t> rng;
-    DevBuf<unsigned long long> tmask;
+    DevBuf<unsigned long long> tmask, tmask_t;
     hipStream_t stream = nullptr;   // lanes run on these when there is more than one
     hipEvent_t done = nullptr;
     void release() {
         counts.release(); hit_id.release(); blist.release(); hit_t.release();
         for (int q = 0; q < 2; ++q) { ray_o[q].release(); ray_d[q].release(); }
         vP.release(); vN.release(); vS.release(); contrib.release(); direct.release(); stackA.release(); stackB.release(); radiance.release();
-        lray.release(); linv.release(); rng.release(); tmask.release();
+        lray.release(); linv.release(); rng.release(); tmask.release(); tmask_t.release();
     }
 };
 
@@ -152,7 +153,7 @@ struct rt_scene {
 
     bool opt_stats = false, opt_timing = false;
     uint64_t opt_max_paths = 1ull << 24;
-    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 16, opt_phase_bias = 16, opt_shadow_waves = 8, opt_light_waves = 4, opt_hot = 1, opt_extend_persist = 1, opt_extend_refill = 24, opt_extend_inner = 20, opt_extend_grid = 8, opt_lanes = 3;
+    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 16, opt_phase_bias = 16, opt_shadow_waves = 8, opt_light_waves = 4, opt_hot = 1, opt_extend_persist = 1, opt_extend_refill = 24, opt_extend_inner = 20, opt_extend_grid = 8, opt_lanes = 3, opt_shaft = 8;
     uint64_t opt_lane_min_pixels = 65536;
     uint32_t grid_max = 2048;
 
@@ -776,6 +777,7 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
             if (!rc && persist) rc = w.linv.ensure(cap_slots);
             if (!rc && persist) rc = w.blist.ensure(cap_slots);
             if (!rc && persist) rc = w.tmask.ensure(cap_slots / 64);
+            if (!rc && persist) rc = w.tmask_t.ensure(cap_slots / 64);
             if (!rc && !persist && !in_wave) rc = w.contrib.ensure(cap_paths * (nlL ? nlL : 1));
             if (!rc) rc = w.direct.ensure(cap_paths);
             if (!rc) rc = w.stackA.ensure(per_level);
@@ -807,7 +809,7 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
         for (int q = 0; q < 2; ++q) { pc.ray_o[q] = w.ray_o[q].p; pc.ray_d[q] = w.ray_d[q].p; }
         pc.hit_id = w.hit_id.p; pc.hit_t = w.hit_t.p;
         pc.vP = w.vP.p; pc.vN = w.vN.p; pc.rng = w.rng.p; pc.contrib = w.contrib.p; pc.direct = w.direct.p; pc.in_wave = in_wave ? 1u : 0u;
-        pc.lray = w.lray.p; pc.linv = w.linv.p; pc.blist = w.blist.p; pc.tmask = w.tmask.p; pc.persist = persist ? 1u : 0u;
+        pc.lray = w.lray.p; pc.linv = w.linv.p; pc.blist = w.blist.p; pc.tmask = w.tmask.p; pc.tmask_t = w.tmask_t.p; pc.shaft_steps = s->opt_shaft; pc.persist = persist ? 1u : 0u;
         pc.stackA = w.stackA.p; pc.stackB = w.stackB.p; pc.radiance = w.radiance.p; pc.accum = s->w_accum.p;
         pc.jump = s->w_jump.p; pc.stats = s->w_stats.p; pc.rgba = rgba_dev;
         pc.preview = (progress && host_rgba) ? 1u : 0u;
@@ -1226,6 +1228,7 @@ int rt_get_counters(const rt_scene* cs, rt_counters* out) {
     out->closest_inner = st[ST_C_INNER]; out->closest_tris = st[ST_C_TRIS]; out->closest_sphs = st[ST_C_SPHS];
     out->shadow_inner = st[ST_S_INNER]; out->shadow_tris = st[ST_S_TRIS]; out->shadow_sphs = st[ST_S_SPHS]; out->shadow_wide = st[ST_S_WIDE];
     for (int k = 0; k < 8; ++k) out->trace_steps[k] = st[ST_P_NODE_STEPS + k];
+    for (int k = 0; k < 4; ++k) out->shaft[k] = st[ST_SHAFT_TRIED + k];
     out->closest_hits_tri = st[ST_HITS_TRI]; out->closest_hits_sph = st[ST_HITS_SPH];
     double ms[4] = {0, 0, 0, 0};
     for (size_t i = 0; i < s->events_used; ++i) {
@@ -1257,6 +1260,7 @@ int rt_set_option(rt_scene* s, const char* name, uint64_t value) {
     else if (n == "extend_refill") { s->opt_extend_refill = value > 64 ? 64 : (value < 1 ? 1 : (uint32_t)value); s->dev.extend_refill_min = s->opt_extend_refill; }
     else if (n == "extend_inner") { s->opt_extend_inner = value > 64 ? 64 : (uint32_t)value; s->dev.extend_inner_min = s->opt_extend_inner; }
     else if (n == "extend_grid") s->opt_extend_grid = value < 1 ? 1 : (uint32_t)value;
+    else if (n == "shaft") s->opt_shaft = value > RT_STACK_LDS ? RT_STACK_LDS : (uint32_t)value;
     else if (n == "inner_min") { s->opt_inner_min = value > 64 ? 64 : (uint32_t)value; s->dev.inner_min = s->opt_inner_min; }
     else return fail(RT_ERR_INVALID, "unknown option '" + n + "'");
     return RT_OK;
@@ -1270,7 +1274,7 @@ int rt_get_option(const rt_scene* s, const char* name, uint64_t* value) {
         {"persist", s->opt_persist}, {"hot", s->opt_hot}, {"shadow_waves", s->opt_shadow_waves}, {"light_waves", s->opt_light_waves},
         {"refill_min", s->opt_refill_min}, {"phase_bias", s->opt_phase_bias}, {"inner_min", s->opt_inner_min}, {"lanes", s->opt_lanes},
         {"lane_min_pixels", s->opt_lane_min_pixels}, {"extend_persist", s->opt_extend_persist}, {"extend_refill", s->opt_extend_refill},
-        {"extend_inner", s->opt_extend_inner}, {"extend_grid", s->opt_extend_grid}};
+        {"extend_inner", s->opt_extend_inner}, {"extend_grid", s->opt_extend_grid}, {"shaft", s->opt_shaft}};
     for (const auto& e : table)
         if (n == e.name) { *value = e.v; return RT_OK; }
     return fail(RT_ERR_INVALID, "unknown option '" + n + "'");

@@ -41,7 +41,6 @@ namespace rt {
 #define RT_INFO_BLOCKER 0x80000000u
 #define RT_HOT 2                // occluders tested in k_light before any traversal, per light
 #define RT_HOT_LIGHTS 4         // lights whose occluder cache travels in k_light's kernel arguments (further lights have none)
-#define RT_CHUNK 512u           // persistent kernels: consecutive queue entries a wave takes at a time
 
 struct DevScene {
     const float4* nodes;     // 4 x float4 per inner node (64 B)
@@ -80,6 +79,7 @@ struct HotRec {
 struct HotTable {
     HotRec rec[RT_HOT_LIGHTS][RT_HOT];
 };
+static_assert(RT_HOT == 2, "k_light's shaft skips exactly the two cache records of a light");
 
 struct TravStats {
     uint32_t inner, tris, sphs, wide;
@@ -109,6 +109,8 @@ struct PassCtx {
     float4* direct;                  // per vertex: light-sample sum (in_wave)
     uint32_t in_wave;                // nlL divides 64: k_shadow sums a vertex's light samples inside the wave
     unsigned long long* tmask;       // per row (64 vertices x one light sample), k_light: the vertices whose ray is not yet settled as blocked
+    unsigned long long* tmask_t;     // per row: those of them k_trace_p still has to trace (tmask minus the rays a clear shaft settles as visible)
+    uint32_t shaft_steps;            // k_light: node budget of the shaft walk per (vertex, light); 0 = no shafts
     float4* lray;                    // those rays, packed at the front of their row in lane order: (wi, distance to the light sample; its sign bit is set
                                      // by k_trace_p / k_binary when the ray is occluded: all k_shade_b reads of a ray)
     float4* linv;                    // same places, for the traversal: (1/d of the box test, word: RT_LR_* | occlusion-BVH record of the object the ray starts on)
@@ -125,7 +127,8 @@ struct PassCtx {
 
 // traversal work is counted per ray class: [ST_C_*] closest-hit rays, [ST_S_*] shadow (any-hit) rays
 enum { ST_RAYS_CLOSEST = 0, ST_RAYS_SHADOW, ST_C_INNER, ST_C_TRIS, ST_C_SPHS, ST_S_INNER, ST_S_TRIS, ST_S_SPHS, ST_HITS_TRI, ST_HITS_SPH, ST_S_WIDE,
-       ST_P_NODE_STEPS, ST_P_NODE_LANES, ST_P_PRIM_STEPS, ST_P_PRIM_LANES, ST_P_REFILLS, ST_P_REFILL_LANES, ST_P_BOX_MISS, ST_P_SPARE, ST_COUNT };
+       ST_P_NODE_STEPS, ST_P_NODE_LANES, ST_P_PRIM_STEPS, ST_P_PRIM_LANES, ST_P_REFILLS, ST_P_REFILL_LANES, ST_P_BOX_MISS, ST_P_SPARE,
+       ST_SHAFT_TRIED, ST_SHAFT_CLEAR, ST_SHAFT_STEPS, ST_SHAFT_RAYS, ST_COUNT };
 
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ vec3 xyz(float4 v) { return mk(v.x, v.y, v.z); }
@@ -613,6 +616,139 @@ __device__ __forceinline__ bool wide_prim_step(const DevScene& sc, const BoxRay&
     cur = rest;
     if (!cur && st.sp > 0) cur = st.pop();
     return false;
+}
+
+// ---- Shafts: the light samples of one path vertex as ONE beam (no reference counterpart) ------------------------------------
+// The L rays a vertex p sends to a light all start at p and end on the light's sphere, and most beams hit nothing: each of the rays
+// that k_light cannot settle then walks the occlusion BVH from the root only to find no candidate.  shaft_clear() makes that walk once
+// per (vertex, light): it answers "could wide_child_mask() pass, for ANY ray from p to a point of the light's box, at a slot that
+// holds a primitive record (other than the records in `skip`, which k_light tests itself)?".  If not, k_trace_p would hand no
+// candidate to any of these rays and leave every one of them unblocked; they are settled as visible without being traced.  The
+// answer is one-sided by construction: `false` ("not clear") only costs the traversal that would have run anyway.
+//
+// Geometry.  The rays lie in the convex hull of p and the light's box B_L, i.e. { p + tau w : w in [a, c] (per axis), tau >= 0 } with
+// a = B_L.min - p, c = B_L.max - p.  A child box [lo, hi] meets it iff one tau satisfies, on every axis,
+//     tau a <= hi - p     and     tau c >= lo - p
+// (the cross-section of the hull at tau is the box p + tau [a, c]).  Each inequality bounds tau from one side: the first from below when
+// a < 0 (tau >= (hi - p) / a) and from above when a > 0; the second from below when c > 0 and from above when c < 0.  So per axis
+// VA = (hi - p) / a and VC = (lo - p) / c are evaluated like the near / far plane distances of a ray, and the child is entered iff
+// max(lower bounds, 0) <= min(upper bounds, tau_max).
+//
+// Why it dominates the per-ray test (wide_child_mask above, rays with wide_ray_ok only; the others go to k_binary whatever the shaft
+// says).  Let that test pass for a ray (p, wi) at a slot with planes lo, hi: some t* in [0, lim] has tn <= t* <= tf, so the point
+// X = p + t* u (u the box ray's direction, real arithmetic on its float components) lies in the slot's box grown per axis by
+// eps <= 1.4 * 2^-20 (256 * 2^e + |g - p|) (the pad of that test plus its rounding, times |u| |1/u| ~ 1).  u is ps / |ps| with each
+// component off by under 2^-21 relative (the sample point, ps = sp - p, two normalisations, all correctly rounded), and every sample
+// point lies in B_L grown by 2^-21 (|centre| + r) (|random_sphere| <= 1 + 2^-22 per component).  Hence X = p + tau w with w in [a, c]
+// once a and c are moved outward by 2^-18 (|centre| + r + |p|), and tau = t* / |w| <= lim / (d_s (1 - 2^-20)) <= 1 + 2^-9 max(1, 1 / d_min),
+// d_min a lower bound of the distance from p to B_L.  The box of the slot grown by eps therefore meets the hull below tau_max, and the
+// bounds below — pad 2^-18 (|c| + 256 |s|), i.e. 4 * 2^-20 (...) in the units of tau, against eps' 1.4 and this function's own rounding of
+// under 0.4 — pass.  Nodes that hold an ill-conditioned triangle have no far limit in the per-ray test (prune_limit) and none here.
+// All operands are kept finite (coordinates up to 2^20, |a|, |c| >= 2^-20: shaft_make), so no bound is ever NaN.
+struct Shaft {
+    float px, py, pz;
+    float iax, iay, iaz;   // 1 / a per axis (a < 0 or a > 0, never 0)
+    float icx, icy, icz;   // 1 / c
+    float tmax;
+};
+#define RT_SHAFT_COORD_MAX 1048576.0f   // 2^20
+// The hull of p and the sphere light (centre, r)'s box.  False: no shaft for this pair (p inside the light's box, or coordinates beyond 2^20).
+__device__ __forceinline__ bool shaft_make(vec3 p, float4 cr, Shaft* sh) {
+    const float r = cr.w;
+    const bool sane = fabsf(p.x) <= RT_SHAFT_COORD_MAX && fabsf(p.y) <= RT_SHAFT_COORD_MAX && fabsf(p.z) <= RT_SHAFT_COORD_MAX &&
+                      fabsf(cr.x) <= RT_SHAFT_COORD_MAX && fabsf(cr.y) <= RT_SHAFT_COORD_MAX && fabsf(cr.z) <= RT_SHAFT_COORD_MAX && r >= 0.0f && r <= RT_SHAFT_COORD_MAX;
+    float a[3], c[3];
+    const float pc[3] = {p.x, p.y, p.z}, cc[3] = {cr.x, cr.y, cr.z};
+    float dmin = 0.0f;
+    bool all_straddle = true;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float slop = (fabsf(cc[k]) + r + fabsf(pc[k])) * 0x1p-18f;
+        a[k] = ((cc[k] - r) - pc[k]) - slop;
+        c[k] = ((cc[k] + r) - pc[k]) + slop;
+        if (fabsf(a[k]) < 0x1p-20f) a[k] = -0x1p-20f;      // outward: a only ever decreases, c only ever increases
+        if (fabsf(c[k]) < 0x1p-20f) c[k] = 0x1p-20f;
+        const bool straddle = a[k] < 0.0f && c[k] > 0.0f;
+        all_straddle = all_straddle && straddle;
+        if (!straddle) dmin = fmaxf(dmin, a[k] > 0.0f ? a[k] : -c[k]);   // every ray is at least this long
+    }
+    sh->px = p.x; sh->py = p.y; sh->pz = p.z;
+    sh->iax = 1.0f / a[0]; sh->iay = 1.0f / a[1]; sh->iaz = 1.0f / a[2];
+    sh->icx = 1.0f / c[0]; sh->icy = 1.0f / c[1]; sh->icz = 1.0f / c[2];
+    sh->tmax = 1.0f + 0x1p-9f * fmaxf(1.0f, 1.0f / (dmin * 0.99f));
+    return sane && !all_straddle;
+}
+// One axis of the shaft test of a node: the constant terms of the four bounds (lower / upper from the a-inequality on the hi planes, lower /
+// upper from the c-inequality on the lo planes; the two that do not apply are -inf / +inf) and the plane steps in units of tau.
+struct ShaftAxis { float sA, sC, kAlo, kAup, kClo, kCup; };
+__device__ __forceinline__ ShaftAxis shaft_axis(float g_minus_p, int e, float ia, float ic) {
+    ShaftAxis x;
+    x.sA = ldexpf(ia, e); x.sC = ldexpf(ic, e);
+    const float cA = g_minus_p * ia, cC = g_minus_p * ic;
+    const float pA = fmaf(256.0f, fabsf(x.sA), fabsf(cA)) * 0x1p-18f, pC = fmaf(256.0f, fabsf(x.sC), fabsf(cC)) * 0x1p-18f;
+    const float inf = __builtin_inff();
+    x.kAlo = ia < 0.0f ? cA - pA : -inf; x.kAup = ia < 0.0f ? inf : cA + pA;
+    x.kClo = ic > 0.0f ? cC - pC : -inf; x.kCup = ic > 0.0f ? inf : cC + pC;
+    return x;
+}
+// bit i set = the hull may meet the box of slot i (the shaft's counterpart of wide_child_mask)
+__device__ __forceinline__ uint32_t shaft_child_mask(const Shaft& sh, float tmax, float4 n0, float4 n2, float4 n3, float4 n4) {
+    const uint32_t meta = __float_as_uint(n0.w);
+    const ShaftAxis X = shaft_axis(n0.x - sh.px, (int)(meta & 0xFFu) - WIDE_EXP_BIAS, sh.iax, sh.icx);
+    const ShaftAxis Y = shaft_axis(n0.y - sh.py, (int)((meta >> 8) & 0xFFu) - WIDE_EXP_BIAS, sh.iay, sh.icy);
+    const ShaftAxis Z = shaft_axis(n0.z - sh.pz, (int)((meta >> 16) & 0xFFu) - WIDE_EXP_BIAS, sh.iaz, sh.icz);
+    const uint32_t lox[2] = {__float_as_uint(n2.x), __float_as_uint(n2.y)}, loy[2] = {__float_as_uint(n2.z), __float_as_uint(n2.w)};
+    const uint32_t loz[2] = {__float_as_uint(n3.x), __float_as_uint(n3.y)}, hix[2] = {__float_as_uint(n3.z), __float_as_uint(n3.w)};
+    const uint32_t hiy[2] = {__float_as_uint(n4.x), __float_as_uint(n4.y)}, hiz[2] = {__float_as_uint(n4.z), __float_as_uint(n4.w)};
+    uint32_t hm = 0u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int w = i >> 2, s = 8 * (i & 3);
+        const float qhx = (float)((hix[w] >> s) & 0xFFu), qlx = (float)((lox[w] >> s) & 0xFFu);
+        const float qhy = (float)((hiy[w] >> s) & 0xFFu), qly = (float)((loy[w] >> s) & 0xFFu);
+        const float qhz = (float)((hiz[w] >> s) & 0xFFu), qlz = (float)((loz[w] >> s) & 0xFFu);
+        float tn = fmaxf(fmaxf(fmaf(qhx, X.sA, X.kAlo), fmaf(qlx, X.sC, X.kClo)), 0.0f);
+        tn = fmaxf(tn, fmaxf(fmaf(qhy, Y.sA, Y.kAlo), fmaf(qly, Y.sC, Y.kClo)));
+        tn = fmaxf(tn, fmaxf(fmaf(qhz, Z.sA, Z.kAlo), fmaf(qlz, Z.sC, Z.kClo)));
+        float tf = fminf(fminf(fmaf(qhx, X.sA, X.kAup), fmaf(qlx, X.sC, X.kCup)), tmax);
+        tf = fminf(tf, fminf(fmaf(qhy, Y.sA, Y.kAup), fmaf(qly, Y.sC, Y.kCup)));
+        tf = fminf(tf, fminf(fmaf(qhz, Z.sA, Z.kAup), fmaf(qlz, Z.sC, Z.kCup)));
+        hm |= tn <= tf ? (1u << i) : 0u;
+    }
+    return hm & ((1u << (meta >> 28)) - 1u);                // slots in use
+}
+// The walk: depth-first over the nodes the hull may meet, at most max_steps (<= RT_STACK_LDS) of them; stops at the first primitive slot it
+// may meet that is not one of `skip`.  lds = this lane's column of a [RT_STACK_LDS][RT_BLOCK] array (one push per step at most).
+__device__ __forceinline__ bool shaft_clear(const DevScene& sc, const Shaft& sh, uint32_t skip0, uint32_t skip1, uint32_t skip2, uint32_t skip3, uint32_t* lds,
+                                            uint32_t max_steps, uint32_t* steps) {
+    uint32_t cur = 1u, n = 0u;   // inner group {node 0}
+    int sp = 0;
+    bool clear = true;
+    while (cur != 0u) {
+        if (n == max_steps) { clear = false; break; }
+        ++n;
+        const uint32_t node = (cur >> 8) + (uint32_t)__ffs((int)(cur & 0xFFu)) - 1u;
+        uint32_t rest = cur & (cur - 1u);
+        if (!(rest & 0xFFu)) rest = 0u;
+        const float4* np = sc.wnodes + 5 * (size_t)node;
+        const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+        const uint32_t hm = shaft_child_mask(sh, __float_as_uint(n1.z) ? __builtin_inff() : sh.tmax, n0, n2, n3, n4);
+        const uint32_t meta = __float_as_uint(n0.w), k = (meta >> 24) & 0xFu, prim_base = __float_as_uint(n1.y);
+        const uint32_t ih = hm & ((1u << k) - 1u);
+        uint32_t ph = hm >> k;
+        const uint32_t r0 = skip0 - prim_base, r1 = skip1 - prim_base, r2 = skip2 - prim_base, r3 = skip3 - prim_base;
+        if (r0 < 8u) ph &= ~(1u << r0);
+        if (r1 < 8u) ph &= ~(1u << r1);
+        if (r2 < 8u) ph &= ~(1u << r2);
+        if (r3 < 8u) ph &= ~(1u << r3);
+        if (ph) { clear = false; break; }
+        const uint32_t b = ih ? ((__float_as_uint(n1.x) << 8) | ih) : 0u;
+        if (b && rest) { lds[sp * RT_BLOCK] = rest; ++sp; }
+        cur = b ? b : rest;
+        if (!cur && sp > 0) { --sp; cur = lds[sp * RT_BLOCK]; }
+    }
+    *steps = n;
+    return clear;
 }
 
 template <bool STATS>
@@ -1130,6 +1266,9 @@ __device__ __forceinline__ size_t ls_slot(uint32_t e, uint32_t j, uint32_t nlL) 
 template <bool STATS, int WAVES>   // WAVES: waves per SIMD the register budget is sized for
 __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx pc, uint32_t level, HotTable hot) {
     TravStats tst = {0, 0, 0, 0, 0};
+    __shared__ uint32_t s_shaft[RT_STACK_LDS * RT_BLOCK];                      // shaft_clear()'s stack, [entry][lane]
+    uint32_t sh_tried = 0u, sh_clear = 0u, sh_steps = 0u, sh_rays = 0u;        // STATS
+    const uint32_t shaft_steps = pc.shaft_steps < RT_STACK_LDS ? pc.shaft_steps : RT_STACK_LDS;
     const uint32_t n = pc.vcounts[level], n_round = (n + 63u) & ~63u;
     const uint32_t nlL = pc.nlL, L = pc.P.light_samples;
     for (uint32_t e0 = blockIdx.x * RT_BLOCK + threadIdx.x; e0 < n_round; e0 += gridDim.x * RT_BLOCK) {
@@ -1170,7 +1309,10 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
             sib_axis = w >> 23;
             sib_d = (sib_axis == 0u ? A.x : (sib_axis == 1u ? A.y : A.z)) - (sib_axis == 0u ? p.x : (sib_axis == 1u ? p.y : p.z));
         }
-        // its own box (Bounded, objects.rs:293-316), relative to the vertex: one slab test serves the triangle and the sphere lanes of a wave
+        // Which vertices try a shaft (a choice of where to spend the walk, nothing more): those on a sphere or on a triangle with an axis-flat
+        // box (a wall).  A vertex on a mesh triangle has its neighbours in every beam it sends.
+        const bool shaft_vertex = shaft_steps != 0u && (self_is_sph || (self_is_tri && (lo3(A.x, B.x, C.x) == hi3(A.x, B.x, C.x) || lo3(A.y, B.y, C.y) == hi3(A.y, B.y, C.y) ||
+                                                                                         lo3(A.z, B.z, C.z) == hi3(A.z, B.z, C.z))));
         const float own_dnx = (self_is_sph ? A.x - A.w : lo3(A.x, B.x, C.x)) - p.x, own_dny = (self_is_sph ? A.y - A.w : lo3(A.y, B.y, C.y)) - p.y,
                     own_dnz = (self_is_sph ? A.z - A.w : lo3(A.z, B.z, C.z)) - p.z;
         const float own_dxx = (self_is_sph ? A.x + A.w : hi3(A.x, B.x, C.x)) - p.x, own_dxy = (self_is_sph ? A.y + A.w : hi3(A.y, B.y, C.y)) - p.y,
@@ -1182,6 +1324,7 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
         uint64_t rng = rng0;                                                   // the vertex's stream: two draws per light sample, in sample order
         size_t row = ls_slot(e0 & ~63u, 0, nlL);                               // first slot of the row of (this tile, sample j): + 64 per sample
         unsigned long long* row_mask = pc.tmask + (size_t)(e0 >> 6) * nlL;    // mask of that row: + 1 per sample
+        unsigned long long* row_mask_t = pc.tmask_t + (size_t)(e0 >> 6) * nlL;
         for (uint32_t g = 0, j = 0; g < pc.n_groups; ++g) {                    // for light in lights (raytracer.rs:266): per-light values stay in registers
           const uint32_t light = sc.lights[g];
           const float4 cr = sc.sph[light - sc.n_tri];
@@ -1201,6 +1344,24 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
               hot_s[h] = sub(p, mk(hr.a[0], hr.a[1], hr.a[2]));
               hot_s2[h] = cross3(hot_s[h], mk(hr.e1[0], hr.e1[1], hr.e1[2]));
               hot_tn[h] = dot3(hot_s2[h], mk(hr.e2[0], hr.e2[1], hr.e2[2]));
+          }
+          // The beam of this vertex towards this light (shaft_clear above): when no primitive record other than the ones tested right here
+          // (the object the rays start on, the light's occluder cache) and the coplanar neighbour — where every ray of the beam fails the
+          // flat-axis rule below, i.e. would carry RT_LR_SKIP_SIB — can be a candidate of any of its rays, the rays not blocked here are visible.
+          bool clear = false;
+          if (shaft_vertex) {
+              Shaft sh;
+              if (shaft_make(p, cr, &sh)) {
+                  const float ia_sib = sib_axis == 0u ? sh.iax : (sib_axis == 1u ? sh.iay : sh.iaz), ic_sib = sib_axis == 0u ? sh.icx : (sib_axis == 1u ? sh.icy : sh.icz);
+                  // skip_sib of every ray: !(sib_d * (1/u) > 0) with u's sign that of the direction interval [a, c] on the flat axis
+                  const bool sib_all = has_sib && (sib_d == 0.0f || (sib_d > 0.0f && ic_sib < 0.0f) || (sib_d < 0.0f && ia_sib > 0.0f));
+                  const uint32_t sk1 = sib_all ? (sc.wsib[self_rec] & RT_W_NO_REC) : RT_W_NO_REC;
+                  const uint32_t sk2 = (has_hot && hot.rec[hg][0].kind != 2u) ? hot.rec[hg][0].rec : RT_W_NO_REC;
+                  const uint32_t sk3 = (has_hot && hot.rec[hg][RT_HOT - 1].kind != 2u) ? hot.rec[hg][RT_HOT - 1].rec : RT_W_NO_REC;
+                  uint32_t steps = 0u;
+                  clear = shaft_clear(sc, sh, self_rec, sk1, sk2, sk3, &s_shaft[threadIdx.x], shaft_steps, &steps);
+                  if (STATS && live) { sh_tried++; sh_steps += steps; sh_clear += clear ? 1u : 0u; }
+              }
           }
           for (uint32_t ls = 0; ls < L; ++ls, ++j, row += 64) {                // for _ in 0..light_samples (raytracer.rs:269)
             const vec3 sp = add(xyz(cr), scale(random_sphere(&rng), cr.w));      // Sphere::random_point, objects.rs:223-226
@@ -1262,20 +1423,38 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
             // case in their slab test, or far-away coordinates, go to k_binary and the binary tree, which has the crate's NaN behaviour
             const bool keep = live && !blocked;
             const unsigned long long m = __ballot(keep);      // the whole wave is here: one row of 64 slots
+            // rays of a clear beam are settled: k_shade_b finds their record, k_trace_p never sees them (k_binary's rays are k_binary's either way)
+            const bool to_trace = keep && !(clear && !binary);
+            const unsigned long long mt = __ballot(to_trace);
+            if (STATS) sh_rays += (keep && !to_trace) ? 1u : 0u;
             if (keep) {
-                const size_t at = row + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                // place in the row: the rays still to trace first, in lane order, then the settled ones (k_trace_p reads a dense run of records)
+                const unsigned long long mine = to_trace ? mt : (m & ~mt);
+                const size_t at = row + (to_trace ? 0u : (uint32_t)__popcll(mt)) + __builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
                 pc.lray[at] = make_float4(wi.x, wi.y, wi.z, d_s);
-                const float sib_i = sib_axis == 0u ? br.ix : (sib_axis == 1u ? br.iy : br.iz);
-                const bool skip_sib = has_sib && !(sib_d * sib_i > 0.0f);
-                pc.linv[at] = make_float4(br.ix, br.iy, br.iz, __uint_as_float(self_rec | (__lane_id() << RT_LR_LANE_SHIFT) | (binary ? RT_LR_BINARY : 0u) |
-                                                                               (skip_sib ? RT_LR_SKIP_SIB : 0u)));
-                if (binary) pc.blist[atomicAdd(&pc.bcounts[level], 1u)] = (uint32_t)at;
+                if (to_trace) {
+                    const float sib_i = sib_axis == 0u ? br.ix : (sib_axis == 1u ? br.iy : br.iz);
+                    const bool skip_sib = has_sib && !(sib_d * sib_i > 0.0f);
+                    pc.linv[at] = make_float4(br.ix, br.iy, br.iz, __uint_as_float(self_rec | (__lane_id() << RT_LR_LANE_SHIFT) | (binary ? RT_LR_BINARY : 0u) |
+                                                                                   (skip_sib ? RT_LR_SKIP_SIB : 0u)));
+                    if (binary) pc.blist[atomicAdd(&pc.bcounts[level], 1u)] = (uint32_t)at;
+                }
             }
-            if (__lane_id() == 0u) row_mask[j] = m;
+            if (__lane_id() == 0u) { row_mask[j] = m; row_mask_t[j] = mt; }
           }
         }
     }
     flush_stats<STATS>(pc.stats, tst, ST_S_INNER);
+    if (STATS) {
+        for (int off = 32; off > 0; off >>= 1) {
+            sh_tried += __shfl_xor(sh_tried, off); sh_clear += __shfl_xor(sh_clear, off);
+            sh_steps += __shfl_xor(sh_steps, off); sh_rays += __shfl_xor(sh_rays, off);
+        }
+        if (__lane_id() == 0u && sh_tried) {
+            atomicAdd(&pc.stats[ST_SHAFT_TRIED], (unsigned long long)sh_tried); atomicAdd(&pc.stats[ST_SHAFT_CLEAR], (unsigned long long)sh_clear);
+            atomicAdd(&pc.stats[ST_SHAFT_STEPS], (unsigned long long)sh_steps); atomicAdd(&pc.stats[ST_SHAFT_RAYS], (unsigned long long)sh_rays);
+        }
+    }
 }
 
 // The light-sample rays k_light put on pc.blist (normally none): Scene::is_occluded on the binary tree, self test included.
@@ -1306,30 +1485,42 @@ __global__ void __launch_bounds__(RT_BLOCK) k_binary(DevScene sc, PassCtx pc, ui
     flush_stats<STATS>(pc.stats, tst, ST_S_INNER);
 }
 
-// Wave state of k_trace_p: a wave owns chunks of RT_CHUNK consecutive slots (chunk = wave index, then
-// + number of waves), reads them a row of 64 at a time, and hands the live rays of a row to its idle
-// lanes as they become free (`pend` = live rays of the current row not yet handed out).
+// Position of the k-th set bit of m (k < popcount(m)).
+__device__ __forceinline__ uint32_t nth_set_bit(unsigned long long m, uint32_t k) {
+    uint32_t w = (uint32_t)m, pos = 0u;
+    const uint32_t c0 = (uint32_t)__popc(w);
+    if (k >= c0) { k -= c0; w = (uint32_t)(m >> 32); pos = 32u; }
+#pragma unroll
+    for (uint32_t s = 16u; s != 0u; s >>= 1) {
+        const uint32_t c = (uint32_t)__popc(w & ((1u << s) - 1u));
+        if (k >= c) { k -= c; w >>= s; pos += s; }
+    }
+    return pos;
+}
+
+// Wave state of k_trace_p: a wave owns windows of 64 consecutive rows (window = wave index, then + number of waves); a row is the 64
+// slots of (vertex tile, light sample).  After k_light's beams most rows hold only a few rays to trace, so the wave takes the masks of a
+// whole window at once (one row per lane), counts them with a prefix sum and hands ray number i of the window — found by a binary search
+// over the prefix sums and a select of the i-th set bit — to its idle lanes as they become free.
 template <bool STATS, int WAVES>   // WAVES: waves per SIMD the register budget is sized for
 __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCtx pc, uint32_t level) {
     RT_STACK_DECL;
-    __shared__ uint32_t s_pub[RT_BLOCK];
-    uint32_t* pub = s_pub + (threadIdx.x & ~63u);
+    // the current window of this wave: per row the rays still to trace (their records lead the row, in lane order) and the number of rays in the rows before
+    __shared__ unsigned long long s_mt[RT_BLOCK];
+    __shared__ uint32_t s_pre[RT_BLOCK];
+    const uint32_t wbase = threadIdx.x & ~63u;
     TravStats tst = {0, 0, 0, 0, 0};
     const uint32_t nlL = pc.nlL;
-    const uint32_t n_slots = ((pc.vcounts[level] + 63u) >> 6) * 64u * nlL;      // < 2^31 (render_impl caps paths * nlL at 2^30)
+    const uint32_t n_rows = ((pc.vcounts[level] + 63u) >> 6) * nlL;             // < 2^25 (render_impl caps paths * nlL at 2^30)
+    const uint32_t n_win = (n_rows + 63u) >> 6;
     const uint32_t n_waves = gridDim.x * (RT_BLOCK / 64);
     const uint32_t lane = __lane_id();
-    uint32_t chunk = __builtin_amdgcn_readfirstlane((blockIdx.x * RT_BLOCK + threadIdx.x) >> 6);
-    uint32_t next = chunk * RT_CHUNK;
-    uint32_t chunk_end = next < n_slots ? (n_slots - next < RT_CHUNK ? n_slots : next + RT_CHUNK) : next;
-    unsigned long long pend = 0ull;
-    uint32_t row_base = 0u, row_tile = 0u;                                     // current row: first slot, vertex tile (vertex = row_tile * 64 + lane)
-    uint32_t tile = next / (64u * nlL), jrow = (next >> 6) % nlL;              // tile and light sample of the row at `next`
+    uint32_t win = __builtin_amdgcn_readfirstlane((blockIdx.x * RT_BLOCK + threadIdx.x) >> 6);   // the window whose masks are in mt_n / mf_n
+    uint32_t w_row0 = 0u, w_total = 0u, w_cursor = 0u;                         // the window in LDS: first row, rays to trace, rays handed out
     const uint32_t refill_min = sc.refill_min, phase_bias = sc.phase_bias;
     uint32_t* words = reinterpret_cast<uint32_t*>(pc.lray);
-    unsigned long long row_full = 0ull;                                        // all rays of the current row: a ray's record is at row_base + (set bits below its lane)
-    // rays to trace of the row at `next` (k_light's vote), loaded one refill ahead
-    unsigned long long m_next = next < n_slots ? pc.tmask[next >> 6] : 0ull;
+    // masks of this lane's row of the next window (k_light's votes), loaded one window ahead
+    unsigned long long mt_n = (win < n_win && win * 64u + lane < n_rows) ? pc.tmask_t[win * 64u + lane] : 0ull;
 
     uint32_t w_steps[6] = {0, 0, 0, 0, 0, 0};   // STATS: wave steps and the lanes that took part (node, primitive, refill)
 
@@ -1342,40 +1533,41 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
     for (;;) {
         const unsigned long long idle = __ballot(cur == 0u);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
-        if ((pend != 0ull || next < n_slots) && n_idle >= refill_min) {
-            if (pend == 0ull) {                                  // next row of 64 slots: which rays are still to trace
-                pend = m_next;
-                row_full = m_next;
-                row_base = next;
-                row_tile = tile;
-                next += 64u;
-                if (++jrow == nlL) { jrow = 0u; ++tile; }
-                if (next == chunk_end) {
-                    chunk += n_waves;
-                    next = chunk * RT_CHUNK;
-                    chunk_end = next < n_slots ? (n_slots - next < RT_CHUNK ? n_slots : next + RT_CHUNK) : next;
-                    tile = next / (64u * nlL);
-                    jrow = (next >> 6) % nlL;
+        if ((w_cursor < w_total || win < n_win) && n_idle >= refill_min) {
+            if (w_cursor == w_total) {                           // next window: its masks to LDS, one row per lane, and the prefix sums of their counts
+                const uint32_t c = (uint32_t)__popcll(mt_n);
+                uint32_t inc = c;
+#pragma unroll
+                for (uint32_t off = 1u; off < 64u; off <<= 1) {
+                    const uint32_t t = __shfl_up(inc, off);
+                    if (lane >= off) inc += t;
                 }
-                m_next = next < n_slots ? pc.tmask[next >> 6] : 0ull;
-                if (pend == 0ull) continue;
+                __builtin_amdgcn_wave_barrier();                 // (the lanes that were reading the previous window are all here)
+                s_mt[wbase + lane] = mt_n;
+                s_pre[wbase + lane] = inc - c;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                w_row0 = win * 64u;
+                w_total = __builtin_amdgcn_readlane(inc, 63);
+                w_cursor = 0u;
+                win += n_waves;
+                mt_n = (win < n_win && win * 64u + lane < n_rows) ? pc.tmask_t[win * 64u + lane] : 0ull;
+                if (w_total == 0u) continue;
             }
-            const uint32_t n_pend = (uint32_t)__popcll(pend);
-            const uint32_t take = n_pend < n_idle ? n_pend : n_idle;
-            const bool offered = ((pend >> lane) & 1ull) != 0ull;
-            const uint32_t prank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pend >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pend, 0u));
-            if (offered && prank < take)     // (lane, place of its record in the row)
-                pub[prank] = lane | (__builtin_amdgcn_mbcnt_hi((uint32_t)(row_full >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)row_full, 0u)) << 8);
-            pend = __ballot(offered && prank >= take);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            const uint32_t left = w_total - w_cursor;
+            const uint32_t take = left < n_idle ? left : n_idle;
             const uint32_t irank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-            const bool mine = cur == 0u && irank < take;
             if (STATS) { w_steps[4]++; w_steps[5] += take; }
-            if (mine) {
-                const uint32_t got = pub[irank], src = got & 63u;
-                slot = row_base + (got >> 8);
-                const uint32_t e = row_tile * 64u + src;
+            if (cur == 0u && irank < take) {
+                const uint32_t idx = w_cursor + irank;           // this lane's ray among the window's
+                uint32_t r = 0u;                                 // its row: the last one with s_pre[row] <= idx
+#pragma unroll
+                for (uint32_t step = 32u; step != 0u; step >>= 1)
+                    if (s_pre[wbase + r + step] <= idx) r += step;
+                const uint32_t k = idx - s_pre[wbase + r];      // ... and its place among the row's rays to trace = the place of its record
+                const uint32_t src = nth_set_bit(s_mt[wbase + r], k);             // its vertex within the tile
+                slot = (w_row0 + r) * 64u + k;
+                const uint32_t e = ((w_row0 + r) / nlL) * 64u + src;
                 const float4 R4 = pc.lray[slot], I4 = pc.linv[slot];
                 const float4 P4 = pc.vP[e];
                 rec_word = __float_as_uint(I4.w);
@@ -1389,7 +1581,7 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
                 st.sp = 0;
                 cur = (rec_word & RT_LR_BINARY) ? 0u : 1u;                     // inner group {node 0}; k_binary's rays are not traced here
             }
-            __builtin_amdgcn_wave_barrier();
+            w_cursor += take;
             continue;
         }
         if (n_idle == 64u) break;
@@ -1463,18 +1655,22 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SB_WAVES) k_shade_b(DevScene sc, 
                         vec3 color = mk(0.0f, 0.0f, 0.0f);
                         const size_t row0 = ls_slot(e & ~63u, g * L, pc.nlL);                                  // first slot of the row of sample s: + 64 s
                         const unsigned long long* mrow = pc.tmask + (size_t)(e >> 6) * pc.nlL + (size_t)g * L;  // mask of that row: + s
+                        const unsigned long long* mrow_t = pc.tmask_t + (size_t)(e >> 6) * pc.nlL + (size_t)g * L;   // ... and which of them were traced
                         for (uint32_t s0 = 0; s0 < L; s0 += RT_SB_BATCH) {                         // RT_SB_BATCH samples in flight, then added in sample order
-                            unsigned long long mk8[RT_SB_BATCH];
+                            unsigned long long mk8[RT_SB_BATCH], mt8[RT_SB_BATCH];
                             uint32_t w[RT_SB_BATCH];
                             float4 r[RT_SB_BATCH];
 #pragma unroll
-                            for (uint32_t k = 0; k < RT_SB_BATCH; ++k) mk8[k] = s0 + k < L ? mrow[s0 + k] : 0ull;
+                            for (uint32_t k = 0; k < RT_SB_BATCH; ++k) { mk8[k] = s0 + k < L ? mrow[s0 + k] : 0ull; mt8[k] = s0 + k < L ? mrow_t[s0 + k] : 0ull; }
 #pragma unroll
                             for (uint32_t k = 0; k < RT_SB_BATCH; ++k) {
                                 w[k] = RT_LR_BLOCKED;
                                 r[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                                 if ((mk8[k] >> lane) & 1ull) {
-                                    const size_t at = row0 + 64 * (size_t)(s0 + k) + (size_t)__popcll(mk8[k] & ((1ull << lane) - 1ull));
+                                    // the row holds the traced rays first, then the ones a clear beam settled, each group in lane order (k_light)
+                                    const unsigned long long below = (1ull << lane) - 1ull;
+                                    const uint32_t place = ((mt8[k] >> lane) & 1ull) ? (uint32_t)__popcll(mt8[k] & below) : (uint32_t)(__popcll(mt8[k]) + __popcll(mk8[k] & ~mt8[k] & below));
+                                    const size_t at = row0 + 64 * (size_t)(s0 + k) + place;
                                     r[k] = pc.lray[at];
                                     w[k] = __float_as_uint(r[k].w);
                                 }

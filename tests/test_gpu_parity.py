@@ -270,14 +270,15 @@ def test_occluder_cache_and_scheduling_switches_do_not_change_a_pixel(gpu):
     p = to_rt_params(op)
     for opts in ({}, {"self_test": 0}, {"refill_min": 1, "phase_bias": 1}, {"refill_min": 64, "phase_bias": 4, "shadow_waves": 5},
                  {"light_waves": 8}, {"extend_persist": 0}, {"extend_persist": 2, "extend_refill": 1, "extend_inner": 1},
-                 {"extend_persist": 2, "extend_refill": 64, "extend_inner": 64, "extend_grid": 1}, {"extend_refill": 7, "extend_inner": 40, "extend_grid": 3}):
+                 {"extend_persist": 2, "extend_refill": 64, "extend_inner": 64, "extend_grid": 1}, {"extend_refill": 7, "extend_inner": 40, "extend_grid": 3},
+                 {"shaft": 0}, {"shaft": 1}, {"shaft": 3, "refill_min": 1}, {"shaft": 16}):
         for k, v in opts.items():
             gsc.set_option(k, v)
         got, cnt = gpu_render(gsc, p)
         assert np.array_equal(got, ref["rgba"]), opts
         assert cnt["rays_shadow"] == ref["occluded_calls"] and cnt["rays_closest"] == ref["intersect_calls"], opts
         for k, v in {"self_test": 1, "refill_min": 16, "phase_bias": 16, "shadow_waves": 8, "light_waves": 4, "extend_persist": 1, "extend_refill": 24,
-                     "extend_inner": 20, "extend_grid": 8}.items():
+                     "extend_inner": 20, "extend_grid": 8, "shaft": 8}.items():
             gsc.set_option(k, v)
     with pytest.raises(Exception):
         gsc.set_option("hot", 0)                           # the cache is chosen at the first render
@@ -291,6 +292,63 @@ def test_occluder_cache_and_scheduling_switches_do_not_change_a_pixel(gpu):
     _, c_hot = gpu_render(gsc, p)
     gsc.set_option("stats", 0)
     assert 0 < c_hot["trace_steps"][5] < c_cold["trace_steps"][5]      # rays handed to k_trace_p: fewer with the cache
+
+
+def _floaters_scene(n_tri=260, n_sph=60, seed=5):
+    """new_specular's room with a second, small lamp low in it (so that path vertices lie beside, below, above and inside the box of a
+    light: every sign class of a beam's direction interval) and many small diffuse triangles and balls floating in the air: beams that
+    are clear, beams a floater barely touches, beams it fills."""
+    from oracle import binding as ob
+    import rustracer_amd as ra
+    e = ra.Scene.new_specular().export()
+    rng = np.random.default_rng(seed)
+    mats = np.concatenate([e["mats"], np.zeros((2, 8), np.uint32)])
+    mats[-2] = np.array([0, 0, 0, 0, 2.5, 2.0, 1.5, 0], np.float32).view(np.uint32); mats[-2][0] = 0          # second lamp
+    mats[-1] = np.array([0, 0.7, 0.7, 0.6, 0, 0, 0, 0], np.float32).view(np.uint32); mats[-1][0] = 0          # floaters
+    c = rng.uniform([-18, -18, -66], [18, 16, -30], (n_tri, 3))
+    tri = np.concatenate([c + rng.normal(scale=rng.uniform(0.05, 1.2, (n_tri, 1)), size=(n_tri, 3)) for _ in range(3)], axis=1).astype(np.float32)
+    nrm = np.tile(np.array([0, 1, 0, 0, 1, 0, 0, 1, 0], np.float32), (n_tri, 1))
+    balls = np.concatenate([rng.uniform([-18, -18, -66], [18, 16, -30], (n_sph, 3)), rng.uniform(0.05, 1.5, (n_sph, 1))], axis=1).astype(np.float32)
+    sph = np.concatenate([e["sph"], np.array([[6.0, -12.0, -45.0, 0.6]], np.float32), balls])
+    sph_mat = np.concatenate([e["sph_mat"], np.array([len(mats) - 2], np.uint32), np.full(n_sph, len(mats) - 1, np.uint32)])
+    args = (np.concatenate([e["tri_pos"], tri]), np.concatenate([e["tri_nrm"], nrm]), np.concatenate([e["tri_mat"], np.full(n_tri, len(mats) - 1, np.uint32)]),
+            sph, sph_mat, mats)
+    return ob.OracleScene.raw(*args), ra.Scene.from_arrays(*args)
+
+
+def test_beams_settle_rays_without_changing_a_pixel(scenes):
+    """k_light walks the occlusion BVH once per (vertex, light) with the hull of the vertex and the light's box ("shaft"); a beam that can
+    meet no primitive record settles its unblocked rays as visible and they never reach k_trace_p.  One-sided by construction, so image and
+    ray counts equal the oracle's for every node budget, and the counters show beams found clear and fewer rays traced."""
+    cases = [(_floaters_scene(), dict(width=112, height=84, spp=3, light_samples=6, bounces=4, seed=17)),
+             (_floaters_scene(n_tri=40, n_sph=4, seed=9), dict(width=96, height=96, spp=2, light_samples=16, bounces=3, seed=3, cam=(3.0, -6.0, -8.0))),
+             (_two_light_scene(), dict(width=80, height=60, spp=3, light_samples=8, bounces=5, seed=23)),
+             (scenes("dragon_small"), dict(width=128, height=96, spp=2, light_samples=8, bounces=4, seed=29)),
+             (scenes("specular_teapot"), dict(width=96, height=72, spp=2, light_samples=8, bounces=6, seed=31))]
+    for (osc, gsc), kw in cases:
+        op = oracle_params(**kw)
+        ref = osc.render(op)
+        p = to_rt_params(op)
+        gsc.set_option("stats", 1)
+        traced = {}
+        try:
+            for budget in (0, 2, 8, 16):
+                gsc.set_option("shaft", budget)
+                got, cnt = gpu_render(gsc, p)
+                assert np.array_equal(got, ref["rgba"]), (kw, budget, int((got != ref["rgba"]).sum()))
+                assert cnt["rays_closest"] == ref["intersect_calls"] and cnt["rays_shadow"] == ref["occluded_calls"], (kw, budget)
+                traced[budget] = cnt["trace_steps"][5]
+                walked, clear, nodes, settled = cnt["shaft"]
+                if budget == 0:
+                    assert walked == 0 and settled == 0
+                else:
+                    assert walked > 0 and nodes <= walked * budget and (clear > 0) == (settled > 0), (kw, budget, cnt["shaft"])
+                    if budget >= 8:
+                        assert clear > 0, (kw, budget, cnt["shaft"])
+            assert traced[16] <= traced[8] <= traced[2] <= traced[0] and traced[16] < traced[0], traced       # a larger budget proves more beams clear
+        finally:
+            gsc.set_option("stats", 0)
+            gsc.set_option("shaft", 8)
 
 
 def test_render_lanes_do_not_change_a_pixel(scenes):

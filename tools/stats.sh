@@ -1,7 +1,14 @@
-# traversal statistics on the GPU box: bash tools/stats.sh "opt=val ..." ...
+# traversal statistics + one-lane kernel times on the GPU box: bash tools/stats.sh "opt=val ..." ...   (each argument is one bench run)
 set -o pipefail
 for o in "$@"; do
   args=""; for kv in $o; do args="$args --opt $kv"; done
   echo "== $o"
-  timeout -k 10 200 python -u bench.py --spp ${SPP:-16} --steps 1 --warmup 1 --cpu-seconds 0 --stats-spp 2 $args 2>&1 | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print(d['value'], d['kernel_ms_last_step']); print(r['per_traced_ray'], r['bytes_per_ray'])" || exit 1
+  timeout -k 10 300 python -u bench.py --spp ${SPP:-16} --steps 2 --warmup 1 --cpu-seconds 0 --stats-spp 2 $args 2>&1 | tail -1 | python3 -c "
+import sys,json
+d=json.loads(sys.stdin.read()); r=d['roofline']; k=r['kernels']
+print('Mrays/s', d['value'], 'ms/step', d['ms_per_step'], 'lanes-overlapped kernel ms', d['kernel_ms_last_step'])
+print('one-lane frame ms', (r.get('exclusive') or {}).get('frame_ms_one_lane'), {n: (v.get('exclusive_avg_launch_ms'), v['launches_per_step']) for n, v in k.items()})
+print('trace per_unit', k.get('k_trace_p', {}).get('per_unit'))
+print('shaft', k.get('k_light', {}).get('shaft'))
+" || exit 1
 done
