@@ -57,9 +57,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        return launch_ranks(a.gpus)          # plain `python bench.py --gpus N`: start the N ranks as a child job, before any GPU call
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
         a.gpus = world
 
     import rustracer_amd as ra
@@ -76,10 +76,13 @@ def main():
     torch.cuda.set_device(dev_index)
     check(lib().rt_init(dev_index))
     dev = torch.device("cuda", dev_index)
-    comm, gather_note = None, None
+    comm, gather_note, comm_desc = None, None, None
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("gloo")
+        if backend != "rccl":
+            gather_note = "RT_BENCH_BACKEND=%s: a rehearsal (%d ranks on %d GPU(s)), tiles gathered through the host with gloo; not a measurement" % (
+                backend, world, torch.cuda.device_count())
         if backend == "rccl":
             def bcast(ident):
                 box = [ident]
@@ -96,6 +99,8 @@ def main():
                 if comm is not None:
                     comm.destroy()
                 comm = None
+            if comm is not None:
+                comm_desc = comm.describe()
 
     # ---- scene (replicated on every rank; the BVH is built on the host) ----
     dragon_obj = os.path.join(ROOT, "obj", "dragon.obj")
@@ -140,12 +145,27 @@ def main():
         step()
     scene.set_option("timing", 1)
     fence()
+    # HIP events on the launch stream around this rank's own render of every timed step (the lanes fork from and join back into it), and
+    # the library's events around the gather: with tiles dealt t % world an uneven frame shows up as a spread of the per-rank times
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    gather_ms = []
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        final = step()
+    for i in range(a.steps):
+        ev[i][0].record()
+        check(lib().rt_render_device(scene.handle, C.byref(params), frame.data_ptr(), stream))
+        ev[i][1].record()
+        if comm is not None:
+            comm.gather(params, frame.data_ptr(), stream)      # in place: every rank ends up with the whole frame
+        elif world > 1:
+            tg = time.perf_counter()
+            final = tiles.gather_frame(frame, a.width, a.height, tile[0], tile[1], rank, world)
+            gather_ms.append((time.perf_counter() - tg) * 1e3)
     fence()
     elapsed = time.perf_counter() - t0
     scene.set_option("timing", 0)
+    render_ms_rank = sum(e0.elapsed_time(e1) for e0, e1 in ev) / max(a.steps, 1)
+    if comm is not None:
+        gather_ms = [comm.last_gather_ms()]                    # of the last step
 
     cnt = scene.counters()   # counts and HIP-event kernel times of the last timed step of this rank
     lanes = scene.get_option("lanes")
@@ -155,6 +175,13 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     elapsed = float(el.item())
+    per_rank = [render_ms_rank]
+    per_rank_gather = [sum(gather_ms) / len(gather_ms) if gather_ms else 0.0]
+    if world > 1:
+        box = [None] * world
+        dist.all_gather_object(box, (render_ms_rank, per_rank_gather[0]))
+        per_rank = [b[0] for b in box]
+        per_rank_gather = [b[1] for b in box]
     rays_closest, rays_shadow, samples = [float(v) for v in tot.tolist()]
     rays_per_step = rays_closest + rays_shadow
     ms_per_step = elapsed / a.steps * 1e3
@@ -316,11 +343,39 @@ def main():
                                 "light_sampling": round(cnt["kernel_ms_light"], 2), "shade_generate_resolve": round(cnt["kernel_ms_shade"], 2)},
         "roofline": roofline, "cpu_baseline": cpu,
     }
+    if world > 1:
+        out["ranks"] = {"render_ms_per_step": {"min": round(min(per_rank), 3), "max": round(max(per_rank), 3), "per_rank": [round(v, 3) for v in per_rank]},
+                        "gather_ms": {"max": round(max(per_rank_gather), 3), "per_rank": [round(v, 3) for v in per_rank_gather],
+                                      "what": ("HIP events around rt_gather_tiles (pack + ncclAllGather + unpack) of the last step" if comm_desc
+                                               else "host wall time of the gloo gather per step")},
+                        "rccl": comm_desc}
     if gather_note:
         out["gather_note"] = gather_note
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a
+    CHILD process and relay its output (rank 0's JSON line).  This process has not touched the GPU (torch.cuda.device_count() does not
+    initialise it) and never replaces itself: a process that has initialised HIP must not exec.  With fewer GPUs than ranks (a rehearsal on
+    a one-GPU box) the ranks share devices, RCCL cannot start there, and the tiles travel through the host (RT_BENCH_BACKEND=gloo, said in
+    the line's gather_note)."""
+    import socket
+    import subprocess
+    env = dict(os.environ)
+    n_dev = torch.cuda.device_count()
+    if n_dev < n:
+        env.setdefault("RT_BENCH_BACKEND", "gloo")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env)
+    raise SystemExit(proc.returncode)
 
 
 def pmc_kernels(a):

@@ -173,8 +173,10 @@ int rt_get_counters(const rt_scene* scene, rt_counters* out);
  *   "shaft" 0..16 (default 8): k_light walks the occlusion BVH once per (vertex, light) with the convex hull of the vertex and
  *   the light's box, visiting at most that many nodes; a beam that can meet no primitive record settles its unblocked rays as visible
  *   and they skip k_trace_p (0 = off);
- *   "refill_min" (16), "phase_bias" (16), "shadow_waves" (8), "light_waves" (4), "inner_min" (12), "extend_refill" (24),
- *   "extend_inner" (20), "extend_grid" (8 workgroups per CU): scheduling constants. */
+ *   "refill_min" (16), "phase_bias" (16), "shadow_waves" (6), "light_waves" (4), "inner_min" (12), "extend_refill" (24),
+ *   "extend_inner" (20), "extend_grid" (8 workgroups per CU): scheduling constants;
+ *   "fail_after_passes" N (default 0 = never): test hook, the render reports RT_ERR_HIP once N passes are enqueued (the error exits join the
+ *   render lanes like the normal one). */
 int rt_set_option(rt_scene* scene, const char* name, uint64_t value);
 /* The current value of an option of rt_set_option (no reference counterpart). */
 int rt_get_option(const rt_scene* scene, const char* name, uint64_t* value);
@@ -200,9 +202,22 @@ void rt_comm_destroy(rt_comm* comm);
 int rt_gather_tiles(rt_comm* comm, const rt_render_params* params, void* frame_dev, uint32_t bytes_per_pixel, void* stream);
 /* rt_render for one rank of a multi-GPU job: renders this rank's shard (params->shard_index / shard_count must be the communicator's
  * rank / world), gathers every rank's tiles on the device and copies the complete frame to host memory on every rank.  Collective:
- * every rank must call it for every frame, interrupted or not.  comm == NULL is rt_render. */
+ * every rank must call it for every frame, interrupted or not.  comm == NULL is rt_render.
+ * A rank whose local work fails (a HIP error, an interrupt) still enters the collective, with whatever its frame holds, and reports its
+ * error afterwards, so its peers are never left waiting; a rank that cannot even get its buffers aborts the communicator
+ * (ncclCommAbort: the peers' collective then fails instead of hanging) and the communicator is unusable from then on.
+ * Verified on hardware at world = 1 only (the build pool has one GPU per box); the world = 2 path is exercised on CPU ranks with gloo.
+ * Interrupted frames: with a progress word the caller's buffer is refreshed after every round with the running mean of the samples done so
+ * far, so after RT_ERR_INTERRUPTED it holds, for the pixels being rendered when the flag was seen, the image at the samples finished by
+ * then; the reference (src/raytracer.rs:184-204) leaves such pixels untouched and holds only fully sampled ones.  Without a progress word
+ * only fully sampled pixels are written. */
 int rt_render_comm(rt_scene* scene, const rt_render_params* params, rt_comm* comm, uint8_t* rgba,
                    volatile uint32_t* progress, const volatile uint32_t* interrupt);
+/* Which RCCL the communicator runs on: "RCCL <version code> from <path of the shared object that provides ncclAllGather>" (a process that has
+ * loaded PyTorch resolves to the copy PyTorch ships, a plain C++ host to /opt/rocm/lib/librccl.so: one RCCL per process either way). */
+const char* rt_comm_describe(const rt_comm* comm);
+/* Milliseconds between the HIP events around the last gather on this communicator (pack + ncclAllGather + unpack); waits for it. */
+int rt_comm_last_gather_ms(rt_comm* comm, double* ms);
 
 /* ---- host-side helpers mirroring the reference's scene constructors ---- */
 /* ScreenParams::from_config (src/raytracer.rs:110-124); fills width..z of *params. */

@@ -149,6 +149,8 @@ extern "C" {
     pub fn rt_comm_destroy(comm: *mut rt_comm);
     pub fn rt_gather_tiles(comm: *mut rt_comm, params: *const rt_render_params, frame_dev: *mut c_void, bytes_per_pixel: u32, stream: *mut c_void) -> c_int;
     pub fn rt_render_comm(scene: *mut rt_scene, params: *const rt_render_params, comm: *mut rt_comm, rgba: *mut u8, progress: *mut u32, interrupt: *const u32) -> c_int;
+    pub fn rt_comm_describe(comm: *const rt_comm) -> *const c_char;
+    pub fn rt_comm_last_gather_ms(comm: *mut rt_comm, ms: *mut f64) -> c_int;
 
     pub fn rt_screen_params(width: u32, height: u32, fov_radians: f32, params: *mut rt_render_params);
     pub fn rt_scene_new_named(name: *const c_char, obj_path: *const c_char, out: *mut *mut rt_scene) -> c_int;

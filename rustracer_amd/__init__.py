@@ -5,5 +5,5 @@ Host-side mirror of the reference API (Scene / Raytracer / Canvas) over librustr
 """
 from ._lib import RtError, RenderParams, Material  # noqa: F401
 from .scene import Scene, dragon_standin_mesh, DRAGON_STANDIN_FULL, DRAGON_STANDIN_SMALL  # noqa: F401
-from .raytracer import Config, RenderConfig, RenderingMode, SharedPixelBuffer, Raytracer, RaytracerInner, make_params  # noqa: F401
+from .raytracer import Config, RenderConfig, RenderQuality, RenderingMode, SharedPixelBuffer, Raytracer, RaytracerInner, make_params  # noqa: F401
 from .canvas import Canvas  # noqa: F401

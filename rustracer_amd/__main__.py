@@ -5,7 +5,7 @@ import os
 import sys
 import time
 
-from . import Config, Raytracer, Scene
+from . import Config, Raytracer, RenderQuality, Scene
 from ._lib import RT_DIRECT_HEMISPHERE, RT_DIRECT_IMPORTANCE, check, lib
 
 
@@ -24,7 +24,10 @@ def main(argv=None):
     ap.add_argument("--seed", type=lambda v: int(v, 0), default=0x5EED, help="RNG seed (the reference is time-seeded)")
     ap.add_argument("--hemisphere", action="store_true", help="hemisphere direct-lighting estimator (README.md:9)")
     ap.add_argument("--obj-dir", default="obj")
+    ap.add_argument("--preset", choices=list(RenderQuality.PRESETS), help="the (spp, light samples) pairs of the reference's quality panel (src/gui.rs:56-74)")
     a = ap.parse_args(argv)
+    if a.preset:
+        a.s, a.l = RenderQuality.get(a.preset)
     config = Config(screen_width=a.w, screen_height=a.h, samples_per_pixel=a.s, light_samples=a.l, bounces=a.b, debug=a.debug,
                     high_dpi=a.high_dpi, image_mode=a.image_mode, single_threaded=a.single_threaded, seed=a.seed,
                     direct_estimator=RT_DIRECT_HEMISPHERE if a.hemisphere else RT_DIRECT_IMPORTANCE)

@@ -65,7 +65,7 @@ class Counters(C.Structure):
 EXPORTS = [
     "rt_last_error", "rt_init", "rt_scene_create", "rt_scene_destroy", "rt_scene_info_get", "rt_set_global_option", "rt_scene_build_info", "rt_scene_lights", "rt_scene_bvh", "rt_scene_wide_bvh",
     "rt_render", "rt_render_device", "rt_cast_primary", "rt_cast_primary_device", "rt_cast_primary_noalloc", "rt_intersect_rays", "rt_occluded_rays",
-    "rt_get_counters", "rt_set_option", "rt_get_option", "rt_tiles_per_shard", "rt_tiles_pack", "rt_tiles_unpack", "rt_comm_unique_id", "rt_comm_init_rank", "rt_comm_destroy", "rt_gather_tiles", "rt_render_comm", "rt_screen_params",
+    "rt_get_counters", "rt_set_option", "rt_get_option", "rt_tiles_per_shard", "rt_tiles_pack", "rt_tiles_unpack", "rt_comm_unique_id", "rt_comm_init_rank", "rt_comm_destroy", "rt_gather_tiles", "rt_render_comm", "rt_comm_describe", "rt_comm_last_gather_ms", "rt_screen_params",
     "rt_scene_new_named", "rt_scene_new_dragon_mesh", "rt_scene_export", "rt_make_dragon_standin", "rt_debug_math", "rt_debug_rng", "rt_debug_exact",
 ]
 
@@ -119,6 +119,9 @@ def lib():
     L.rt_comm_destroy.restype = None
     L.rt_gather_tiles.argtypes = [vp, C.POINTER(RenderParams), vp, u32, vp]
     L.rt_render_comm.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, vp]
+    L.rt_comm_describe.argtypes = [vp]
+    L.rt_comm_describe.restype = C.c_char_p
+    L.rt_comm_last_gather_ms.argtypes = [vp, C.POINTER(C.c_double)]
     L.rt_screen_params.argtypes = [u32, u32, f32, C.POINTER(RenderParams)]
     L.rt_screen_params.restype = None
     L.rt_scene_new_named.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(vp)]

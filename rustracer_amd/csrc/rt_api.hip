@@ -2,6 +2,7 @@
 // scheduling of the wavefront kernels (rt_kernels.h) and the debug probes.  gfx950 only.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <dlfcn.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -153,8 +154,9 @@ struct rt_scene {
 
     bool opt_stats = false, opt_timing = false;
     uint64_t opt_max_paths = 1ull << 24;
-    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 16, opt_phase_bias = 16, opt_shadow_waves = 8, opt_light_waves = 4, opt_hot = 1, opt_extend_persist = 1, opt_extend_refill = 24, opt_extend_inner = 20, opt_extend_grid = 8, opt_lanes = 3, opt_shaft = 8;
+    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 16, opt_phase_bias = 16, opt_shadow_waves = 6, opt_light_waves = 4, opt_hot = 1, opt_extend_persist = 1, opt_extend_refill = 24, opt_extend_inner = 20, opt_extend_grid = 8, opt_lanes = 3, opt_shaft = 8;
     uint64_t opt_lane_min_pixels = 65536;
+    uint64_t opt_fail_after_passes = 0;          // test hook: render_impl reports a failure once this many passes are enqueued (0 = never)
     uint32_t grid_max = 2048;
 
     std::vector<EventPair> events;
@@ -822,8 +824,12 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
         for (uint32_t k = 0; k < n_lanes; ++k) HIP_TRY(hipStreamWaitEvent(streams[k], s->ev_fork, 0));
     }
 
+    // One exit for every outcome: whatever happens while the passes are enqueued (an interrupt, a failed HIP call, the injected failure of the
+    // tests), the lane streams are joined back into the caller's stream below before the call returns, so the caller never owns a frame that a
+    // lane may still be writing.
     // passes of a lane: its pixels in chunks of npix_chunk, the samples of a chunk in chunks of spc; lanes take turns at enqueueing a pass
     uint64_t total_passes = 0, done = 0;
+    const uint64_t fail_at = s->opt_fail_after_passes;   // test hook (rt_set_option "fail_after_passes"): report a failure once that many passes are enqueued
     uint64_t at_pix[RT_MAX_LANES];
     uint32_t at_s0[RT_MAX_LANES];
     for (uint32_t k = 0; k < n_lanes; ++k) {
@@ -832,8 +838,10 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
         at_pix[k] = lane_begin[k];
         at_s0[k] = 0;
     }
+    auto run_passes = [&]() -> int {
     for (bool any = true; any;) {
         any = false;
+        if (fail_at && done >= fail_at) return fail(RT_ERR_HIP, "injected failure after " + std::to_string(done) + " passes (option fail_after_passes)");
         if (interrupt && *interrupt && done < total_passes) {   // between rounds: every lane has finished the same number of passes
             for (uint32_t j = 0; j < n_lanes; ++j) HIP_TRY(hipStreamSynchronize(streams[j]));
             return fail(RT_ERR_INTERRUPTED, "render interrupted");
@@ -923,11 +931,23 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
             if (progress) *progress = (uint32_t)((float)done / (float)total_passes * 100.0f);   // raytracer.rs:191, 213
         }
     }
-    if (n_lanes > 1)
+    return RT_OK;
+    };
+    const int rc_run = run_passes();
+    if (n_lanes > 1) {
+        // join: the caller's stream waits for every lane, error or not; after an error or an interrupt the host waits as well
+        int rc_join = RT_OK;
         for (uint32_t k = 0; k < n_lanes; ++k) {
-            HIP_TRY(hipEventRecord(s->ws[k].done, streams[k]));
-            HIP_TRY(hipStreamWaitEvent(stream, s->ws[k].done, 0));
+            if (hipEventRecord(s->ws[k].done, streams[k]) != hipSuccess || hipStreamWaitEvent(stream, s->ws[k].done, 0) != hipSuccess) {
+                (void)hipStreamSynchronize(streams[k]);
+                if (!rc_join) rc_join = RT_ERR_HIP;
+            }
         }
+        if (rc_run)
+            for (uint32_t k = 0; k < n_lanes; ++k) (void)hipStreamSynchronize(streams[k]);
+        if (!rc_run && rc_join) return fail(RT_ERR_HIP, "joining the render lanes failed");
+    }
+    if (rc_run) return rc_run;
     // samples = owned valid pixels * spp (host arithmetic; edge tiles are clipped)
     {
         uint64_t valid = 0;
@@ -1092,24 +1112,44 @@ int rt_render_device(rt_scene* s, const rt_render_params* params, void* rgba_dev
 }
 
 int rt_gather_tiles(rt_comm* c, const rt_render_params* P, void* frame_dev, uint32_t bytes_per_pixel, void* stream);
+}  // extern "C"
+namespace {
+int gather_prepare(rt_comm* c, const rt_render_params* P, uint32_t bytes_per_pixel);
+int gather_run(rt_comm* c, const rt_render_params* P, void* frame_dev, uint32_t bytes_per_pixel, hipStream_t stream);
+void comm_abort(rt_comm* c);
+}  // namespace
+extern "C" {
 
+// Two phases, so that a rank that fails does not leave its peers waiting in ncclAllGather for ever:
+//   1. everything local that can fail (parameter checks, the frame and gather buffers, the upload, the render itself);
+//   2. the collective, which this rank enters whenever its buffers exist — after a failed or interrupted render too, with whatever its
+//      frame holds — and only then reports the local error.  If the buffers themselves could not be had, the communicator is aborted
+//      (ncclCommAbort), which makes the peers' collective return an error instead of hanging; the communicator is unusable afterwards.
 int rt_render_comm(rt_scene* s, const rt_render_params* params, rt_comm* comm, uint8_t* rgba, volatile uint32_t* progress, const volatile uint32_t* interrupt) {
-    if (!s || !rgba) return fail(RT_ERR_INVALID, "NULL argument");
+    if (!s || !rgba) { comm_abort(comm); return fail(RT_ERR_INVALID, "NULL argument"); }
     int rc;
-    if ((rc = validate_params(params))) return rc;
+    if ((rc = validate_params(params))) { const std::string why = g_error; comm_abort(comm); return fail(rc, why); }
     BIND(s->device);
     const size_t bytes = (size_t)params->width * params->height * 4;
-    if ((rc = s->w_frame.ensure(bytes))) return rc;
-    HIP_TRY(hipMemcpy(s->w_frame.p, rgba, bytes, hipMemcpyHostToDevice));   // pixels of other shards / of an interrupted render stay as the caller has them
-    rc = render_impl(s, params, s->w_frame.p, nullptr, progress, interrupt, rgba);
-    // every rank takes part in the collective, interrupted or not: a rank that skipped it would leave the others waiting
-    if (comm && (rc == RT_OK || rc == RT_ERR_INTERRUPTED)) {
-        const int rg = rt_gather_tiles(comm, params, s->w_frame.p, 4, nullptr);
-        if (rg) rc = rg;
+    rc = s->w_frame.ensure(bytes);
+    if (!rc && comm) rc = gather_prepare(comm, params, 4);
+    if (rc) { const std::string why = g_error; comm_abort(comm); return fail(rc, why + (comm ? " (communicator aborted: the peers' collective fails instead of waiting)" : "")); }
+    std::string why;
+    if (hipMemcpy(s->w_frame.p, rgba, bytes, hipMemcpyHostToDevice) != hipSuccess) {   // pixels of other shards / of an interrupted render stay as the caller has them
+        rc = RT_ERR_HIP; why = "copying the caller's frame to the device failed";
+    } else {
+        rc = render_impl(s, params, s->w_frame.p, nullptr, progress, interrupt, rgba);
+        if (rc) why = g_error;
     }
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(rgba, s->w_frame.p, bytes, hipMemcpyDeviceToHost));   // partial pixels stay in the buffer on interrupt
-    return rc;
+    if (comm) {
+        const int rg = gather_run(comm, params, s->w_frame.p, 4, nullptr);
+        if (rg && !rc) { rc = rg; why = g_error; }
+    }
+    if (hipDeviceSynchronize() != hipSuccess && !rc) { rc = RT_ERR_HIP; why = "hipDeviceSynchronize failed after the render"; }
+    if ((rc == RT_OK || rc == RT_ERR_INTERRUPTED) && hipMemcpy(rgba, s->w_frame.p, bytes, hipMemcpyDeviceToHost) != hipSuccess) {   // partial pixels stay in the buffer on interrupt
+        rc = RT_ERR_HIP; why = "copying the frame back failed";
+    }
+    return rc ? fail(rc, why) : RT_OK;
 }
 
 int rt_render(rt_scene* s, const rt_render_params* params, uint8_t* rgba, volatile uint32_t* progress, const volatile uint32_t* interrupt) {
@@ -1260,6 +1300,7 @@ int rt_set_option(rt_scene* s, const char* name, uint64_t value) {
     else if (n == "extend_refill") { s->opt_extend_refill = value > 64 ? 64 : (value < 1 ? 1 : (uint32_t)value); s->dev.extend_refill_min = s->opt_extend_refill; }
     else if (n == "extend_inner") { s->opt_extend_inner = value > 64 ? 64 : (uint32_t)value; s->dev.extend_inner_min = s->opt_extend_inner; }
     else if (n == "extend_grid") s->opt_extend_grid = value < 1 ? 1 : (uint32_t)value;
+    else if (n == "fail_after_passes") s->opt_fail_after_passes = value;
     else if (n == "shaft") s->opt_shaft = value > RT_STACK_LDS ? RT_STACK_LDS : (uint32_t)value;
     else if (n == "inner_min") { s->opt_inner_min = value > 64 ? 64 : (uint32_t)value; s->dev.inner_min = s->opt_inner_min; }
     else return fail(RT_ERR_INVALID, "unknown option '" + n + "'");
@@ -1326,6 +1367,9 @@ int rt_tiles_unpack(const rt_render_params* P, uint32_t shard_index, const void*
 struct rt_comm {
     ncclComm_t comm = nullptr;
     int world = 1, rank = 0, device = 0;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;   // around the last gather
+    bool timed = false;
+    std::string describe;         // which RCCL this process resolved to (path of the shared object, version), for the bench line
     DevBuf<uint8_t> send, recv;   // compact tiles of this rank / of every rank; grow-only: no allocation per frame once sized
 };
 
@@ -1359,6 +1403,14 @@ int rt_comm_init_rank(const uint8_t* id128, int world, int rank, rt_comm** out) 
     c->world = world; c->rank = rank; c->device = g_device;
     const ncclResult_t r = ncclCommInitRank(&c->comm, world, id, rank);
     if (r != ncclSuccess) { delete c; return fail(RT_ERR_HIP, std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); }
+    {
+        // which librccl the dynamic loader bound this library's ncclAllGather to (a process that has torch loaded carries torch's copy too)
+        int ver = 0;
+        (void)ncclGetVersion(&ver);
+        Dl_info info;
+        const char* path = (dladdr((void*)&ncclAllGather, &info) && info.dli_fname) ? info.dli_fname : "?";
+        c->describe = std::string("RCCL ") + std::to_string(ver) + " from " + path;
+    }
     *out = c;
     return RT_OK;
 }
@@ -1368,12 +1420,28 @@ void rt_comm_destroy(rt_comm* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     if (c->comm) (void)ncclCommDestroy(c->comm);
+    if (c->ev_a) (void)hipEventDestroy(c->ev_a);
+    if (c->ev_b) (void)hipEventDestroy(c->ev_b);
     c->send.release(); c->recv.release();
     delete c;
 }
 
 int rt_gather_tiles(rt_comm* c, const rt_render_params* P, void* frame_dev, uint32_t bytes_per_pixel, void* stream) {
     if (!c || !frame_dev) return fail(RT_ERR_INVALID, "NULL argument");
+    int rc;
+    if ((rc = gather_prepare(c, P, bytes_per_pixel))) return rc;   // local checks and buffers first: nothing below fails before the collective is entered
+    return gather_run(c, P, frame_dev, bytes_per_pixel, (hipStream_t)stream);
+}
+
+const char* rt_comm_describe(const rt_comm* c) { return c ? c->describe.c_str() : ""; }
+
+}  // extern "C"
+
+namespace {
+// The part of the gather that can fail on one rank alone: argument checks and the (grow-only) pack / receive buffers.
+int gather_prepare(rt_comm* c, const rt_render_params* P, uint32_t bytes_per_pixel) {
+    if (!c) return fail(RT_ERR_INVALID, "NULL communicator");
+    if (!c->comm) return fail(RT_ERR_INVALID, "the communicator was aborted after an earlier failure");
     int rc;
     if ((rc = validate_params(P))) return rc;
     if (bytes_per_pixel == 0 || bytes_per_pixel % 4) return fail(RT_ERR_INVALID, "bytes_per_pixel must be a multiple of 4");
@@ -1383,10 +1451,42 @@ int rt_gather_tiles(rt_comm* c, const rt_render_params* P, void* frame_dev, uint
     BIND(c->device);
     const size_t bytes = (size_t)rt_tiles_per_shard(P) * P->tile_w * P->tile_h * bytes_per_pixel;   // equal on every rank (padded)
     if ((rc = c->send.ensure(bytes)) || (rc = c->recv.ensure(bytes * (size_t)c->world))) return rc;   // first frame of a geometry only
-    if ((rc = rt_tiles_pack(P, frame_dev, c->send.p, bytes_per_pixel, stream))) return rc;
-    NCCL_TRY(ncclAllGather(c->send.p, c->recv.p, bytes, ncclUint8, c->comm, (hipStream_t)stream));
-    for (int r = 0; r < c->world; ++r)
-        if ((rc = rt_tiles_unpack(P, (uint32_t)r, c->recv.p + bytes * (size_t)r, frame_dev, bytes_per_pixel, stream))) return rc;
+    return RT_OK;
+}
+// pack -> ncclAllGather -> unpack of every rank's tiles on `stream`; HIP events around it give rt_comm_last_gather_ms.
+int gather_run(rt_comm* c, const rt_render_params* P, void* frame_dev, uint32_t bytes_per_pixel, hipStream_t stream) {
+    BIND(c->device);
+    const size_t bytes = (size_t)rt_tiles_per_shard(P) * P->tile_w * P->tile_h * bytes_per_pixel;
+    if (!c->ev_a) { (void)hipEventCreate(&c->ev_a); (void)hipEventCreate(&c->ev_b); }
+    if (c->ev_a) (void)hipEventRecord(c->ev_a, stream);
+    // a failed pack launch must not keep this rank out of the collective: remember it and go on
+    const int rp = rt_tiles_pack(P, frame_dev, c->send.p, bytes_per_pixel, stream);
+    const std::string why_pack = rp ? g_error : std::string();
+    NCCL_TRY(ncclAllGather(c->send.p, c->recv.p, bytes, ncclUint8, c->comm, stream));
+    int rc = rp;
+    for (int r = 0; r < c->world && !rc; ++r) rc = rt_tiles_unpack(P, (uint32_t)r, c->recv.p + bytes * (size_t)r, frame_dev, bytes_per_pixel, stream);
+    if (c->ev_b) { (void)hipEventRecord(c->ev_b, stream); c->timed = true; }
+    return rp ? fail(rp, why_pack) : rc;
+}
+void comm_abort(rt_comm* c) {
+    if (!c || !c->comm) return;
+    (void)ncclCommAbort(c->comm);
+    c->comm = nullptr;
+}
+}  // namespace
+
+extern "C" {
+
+// Milliseconds between the HIP events around the last rt_gather_tiles / rt_render_comm gather (pack + all-gather + unpack); waits for it.
+int rt_comm_last_gather_ms(rt_comm* c, double* ms) {
+    if (!c || !ms) return fail(RT_ERR_INVALID, "NULL argument");
+    *ms = 0.0;
+    if (!c->timed) return RT_OK;
+    BIND(c->device);
+    HIP_TRY(hipEventSynchronize(c->ev_b));
+    float t = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&t, c->ev_a, c->ev_b));
+    *ms = t;
     return RT_OK;
 }
 

@@ -4,6 +4,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <time.h>
 
 #include <chrono>
 #include <string>
@@ -32,7 +34,8 @@ static int usage(FILE* f) {
             "    -s <s>        Sets how many samples per pixel to do\n"
             "    -w <w>        Screen width\n"
             "        --seed <n>     RNG seed (the reference is time-seeded)\n"
-            "        --obj-dir <d>  Directory holding teapot.obj / dragon.obj (default: obj)\n\n"
+            "        --obj-dir <d>  Directory holding teapot.obj / dragon.obj (default: obj)\n"
+            "        --preset <q>   preview | low | medium | high | ultra: the (spp, light samples) pairs of the reference's quality panel\n\n"
             "ENVIRONMENT:\n    SCENE   dragon | teapot | specular (default) | diffuse | triangle | sphere_on_plane | specular_teapot\n"
             "    WORLD_SIZE, RANK, LOCAL_RANK, RT_COMM_ID_FILE   one process per GPU: rank r renders the screen tiles t %% world == r, the tiles are\n"
             "            gathered over RCCL and rank 0 writes the PNG; RT_COMM_ID_FILE is a path all ranks share (rank 0 writes the RCCL id there)\n");
@@ -84,26 +87,40 @@ int main(int argc, char** argv) {
         if (world > 1 || getenv("RT_COMM_ID_FILE")) {
             const char* path = getenv("RT_COMM_ID_FILE");
             if (!path) throw Error(RT_ERR_INVALID, "WORLD_SIZE > 1 needs RT_COMM_ID_FILE (a path every rank can read)");
+            // The file holds an 8-byte job tag and the 128-byte id.  The tag comes from the launcher (RT_JOB_ID, else MASTER_PORT: the same on
+            // every rank of a job, different between jobs), so a file left by another job is not taken for this one's; without either a file
+            // older than a minute before this process started is refused.  Rank 0 removes any old file first and the new one once every rank
+            // holds the communicator (rt_comm_init_rank is collective: all ranks have read the id by then).
             uint8_t id[128];
+            uint64_t tag = 0;
+            const char* job = getenv("RT_JOB_ID") ? getenv("RT_JOB_ID") : getenv("MASTER_PORT");
+            for (const char* q = job; q && *q; ++q) tag = (tag ^ (uint8_t)*q) * 0x100000001B3ull;
+            if (job) tag |= 1ull << 63;
+            const time_t started = time(nullptr);
             if (rank == 0) {
+                (void)remove(path);
                 check(rt_comm_unique_id(id));
                 const std::string tmp = std::string(path) + ".tmp";
                 FILE* f = fopen(tmp.c_str(), "wb");
-                if (!f || fwrite(id, 1, 128, f) != 128) throw Error(RT_ERR_INVALID, "cannot write RT_COMM_ID_FILE");
+                if (!f || fwrite(&tag, 1, 8, f) != 8 || fwrite(id, 1, 128, f) != 128) throw Error(RT_ERR_INVALID, "cannot write RT_COMM_ID_FILE");
                 fclose(f);
                 if (rename(tmp.c_str(), path)) throw Error(RT_ERR_INVALID, "cannot publish RT_COMM_ID_FILE");
             } else {
                 bool got = false;
                 for (int tries = 0; tries < 6000 && !got; ++tries) {   // up to a minute
                     if (FILE* f = fopen(path, "rb")) {
-                        got = fread(id, 1, 128, f) == 128;
+                        uint64_t seen = 0;
+                        struct stat sb;
+                        const bool fresh = job || (fstat(fileno(f), &sb) == 0 && sb.st_mtime + 60 >= started);
+                        got = fread(&seen, 1, 8, f) == 8 && fread(id, 1, 128, f) == 128 && seen == tag && fresh;
                         fclose(f);
                     }
                     if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(10));
                 }
-                if (!got) throw Error(RT_ERR_INVALID, "RT_COMM_ID_FILE did not appear");
+                if (!got) throw Error(RT_ERR_INVALID, "RT_COMM_ID_FILE did not appear (or holds another job's id)");
             }
             check(rt_comm_init_rank(id, world, rank, &comm));
+            if (rank == 0) (void)remove(path);
             raytracer.set_shard((uint32_t)rank, (uint32_t)world, comm);
             raytracer.inner->canvas.save = rank == 0;
         }

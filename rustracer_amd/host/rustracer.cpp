@@ -41,6 +41,41 @@ Config::Config() {
     fov = DEFAULT_FOV_DEGREES * (pi / 180.0f);
 }
 
+const char* render_quality_name(RenderQuality q) {
+    switch (q) {
+        case RenderQuality::Preview: return "Preview (1 spp)";
+        case RenderQuality::Low: return "Low (4 spp)";
+        case RenderQuality::Medium: return "Medium (16 spp)";
+        case RenderQuality::High: return "High (64 spp)";
+        default: return "Ultra (256 spp)";
+    }
+}
+uint32_t render_quality_samples_per_pixel(RenderQuality q) {
+    switch (q) {
+        case RenderQuality::Preview: return 1;
+        case RenderQuality::Low: return 4;
+        case RenderQuality::Medium: return 16;
+        case RenderQuality::High: return 64;
+        default: return 256;
+    }
+}
+uint32_t render_quality_light_samples(RenderQuality q) {
+    switch (q) {
+        case RenderQuality::Preview: return 1;
+        case RenderQuality::Low: return 4;
+        case RenderQuality::Medium: return 8;
+        case RenderQuality::High: return 16;
+        default: return 32;
+    }
+}
+bool render_quality_from_string(const std::string& s, RenderQuality* out) {
+    const struct { const char* n; RenderQuality q; } t[] = {{"preview", RenderQuality::Preview}, {"low", RenderQuality::Low}, {"medium", RenderQuality::Medium},
+                                                            {"high", RenderQuality::High}, {"ultra", RenderQuality::Ultra}};
+    for (const auto& e : t)
+        if (s == e.n) { *out = e.q; return true; }
+    return false;
+}
+
 Config Config::from_args(int argc, char** argv) {
     Config c;
     for (int i = 1; i < argc; ++i) {
@@ -61,6 +96,13 @@ Config Config::from_args(int argc, char** argv) {
         else if (a == "--seed") c.seed = strtoull(value("--seed"), nullptr, 0);
         else if (a == "--hemisphere") c.direct_estimator = RT_DIRECT_HEMISPHERE;
         else if (a == "--obj-dir") c.obj_dir = value("--obj-dir");
+        else if (a == "--preset") {
+            RenderQuality q;
+            const std::string v = value("--preset");
+            if (!render_quality_from_string(v, &q)) throw std::runtime_error("--preset takes preview | low | medium | high | ultra, not '" + v + "'");
+            c.samples_per_pixel = render_quality_samples_per_pixel(q);     // what GuiAction::ChangeQuality does, src/gui.rs / canvas.rs:392-441
+            c.light_samples = render_quality_light_samples(q);
+        }
         else throw std::runtime_error("found argument '" + a + "' which wasn't expected");
     }
     return c;

@@ -30,6 +30,14 @@ const float DEFAULT_FOV_DEGREES = 90.0f;
 const uint32_t DEFAULT_SAMPLES_PER_PIXEL = 4, DEFAULT_LIGHT_SAMPLES = 4, DEFAULT_MAX_BOUNCES = 50;
 const uint64_t DEFAULT_SEED = 0x5EED;   // the reference is time-seeded (src/common.rs:137); this build is reproducible
 
+// Render quality presets (src/gui.rs:35-85): the (samples per pixel, light samples) pairs the reference's panel offers; BASELINE's configs
+// are quoted on them (16 spp -> 8, 64 -> 16, 256 -> 32).  The panel itself is out of scope; `--preset <name>` sets the pair from the command line.
+enum class RenderQuality { Preview, Low, Medium, High, Ultra };
+const char* render_quality_name(RenderQuality q);        // "Preview (1 spp)" ... "Ultra (256 spp)", gui.rs:46-54
+uint32_t render_quality_samples_per_pixel(RenderQuality q);   // 1, 4, 16, 64, 256, gui.rs:56-64
+uint32_t render_quality_light_samples(RenderQuality q);       // 1, 4, 8, 16, 32, gui.rs:66-74
+bool render_quality_from_string(const std::string& s, RenderQuality* out);   // "preview" | "low" | "medium" | "high" | "ultra"
+
 struct Config {
     uint32_t screen_width = DEFAULT_SCREEN_WIDTH, screen_height = DEFAULT_SCREEN_HEIGHT;
     float fov;   // radians
@@ -41,7 +49,7 @@ struct Config {
     uint32_t direct_estimator = RT_DIRECT_IMPORTANCE;
     std::string obj_dir = "obj";
     Config();
-    // src/main.rs:35-105 (clap): -s -l -b -w -h <n>, -d, --high-dpi, -i/--image-mode, --single-threaded; plus --seed, --hemisphere, --obj-dir.
+    // src/main.rs:35-105 (clap): -s -l -b -w -h <n>, -d, --high-dpi, -i/--image-mode, --single-threaded; plus --seed, --hemisphere, --obj-dir, --preset.
     // Throws std::runtime_error on a malformed command line (clap exits with a usage error).
     static Config from_args(int argc, char** argv);
 };

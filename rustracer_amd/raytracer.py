@@ -22,6 +22,20 @@ class RenderingMode:
     Full = _lib.RT_MODE_FULL
 
 
+class RenderQuality:
+    """Render quality presets (src/gui.rs:35-85): name -> (samples per pixel, light samples).  The panel is out of scope; the table is what
+    BASELINE's configs are quoted on (16 spp -> 8, 64 -> 16, 256 -> 32)."""
+    PRESETS = {"preview": (1, 1), "low": (4, 4), "medium": (16, 8), "high": (64, 16), "ultra": (256, 32)}
+    NAMES = {"preview": "Preview (1 spp)", "low": "Low (4 spp)", "medium": "Medium (16 spp)", "high": "High (64 spp)", "ultra": "Ultra (256 spp)"}
+
+    @staticmethod
+    def get(name):
+        try:
+            return RenderQuality.PRESETS[name]
+        except KeyError:
+            raise ValueError("--preset takes %s, not %r" % (" | ".join(RenderQuality.PRESETS), name))
+
+
 class Config:
     """src/main.rs:13-32 with the same defaults."""
 

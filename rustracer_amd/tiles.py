@@ -37,6 +37,18 @@ class Comm:
         from ._lib import check, lib
         check(lib().rt_gather_tiles(self._h, C.byref(params), frame_ptr, bytes_per_pixel, stream))
 
+    def describe(self):
+        """Which RCCL the communicator resolved to (version code and the path of the shared object)."""
+        from ._lib import lib
+        return (lib().rt_comm_describe(self._h) or b"").decode(errors="replace")
+
+    def last_gather_ms(self):
+        """HIP-event time of the last gather (pack + ncclAllGather + unpack); waits for it."""
+        from ._lib import check, lib
+        ms = C.c_double(0.0)
+        check(lib().rt_comm_last_gather_ms(self._h, C.byref(ms)))
+        return ms.value
+
     def destroy(self):
         from ._lib import lib
         if self._h:

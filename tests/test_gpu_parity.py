@@ -277,7 +277,7 @@ def test_occluder_cache_and_scheduling_switches_do_not_change_a_pixel(gpu):
         got, cnt = gpu_render(gsc, p)
         assert np.array_equal(got, ref["rgba"]), opts
         assert cnt["rays_shadow"] == ref["occluded_calls"] and cnt["rays_closest"] == ref["intersect_calls"], opts
-        for k, v in {"self_test": 1, "refill_min": 16, "phase_bias": 16, "shadow_waves": 8, "light_waves": 4, "extend_persist": 1, "extend_refill": 24,
+        for k, v in {"self_test": 1, "refill_min": 16, "phase_bias": 16, "shadow_waves": 6, "light_waves": 4, "extend_persist": 1, "extend_refill": 24,
                      "extend_inner": 20, "extend_grid": 8, "shaft": 8}.items():
             gsc.set_option(k, v)
     with pytest.raises(Exception):

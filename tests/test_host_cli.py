@@ -58,6 +58,18 @@ def test_command_line_errors_and_help():
     assert r.returncode == 2 and "wasn't expected" in r.stderr
     r = subprocess.run([EXE, "-i", "-s"], capture_output=True, text=True)
     assert r.returncode == 2 and "requires a value" in r.stderr
+    r = subprocess.run([EXE, "-i", "--preset", "best"], capture_output=True, text=True)
+    assert r.returncode == 2 and "preview | low | medium | high | ultra" in r.stderr
+
+
+def test_quality_presets_are_the_reference_panels():
+    """The (samples per pixel, light samples) pairs of the reference's quality panel (src/gui.rs:56-74), which BASELINE's configs are quoted
+    on: 16 spp -> 8 light samples, 64 -> 16, 256 -> 32.  Python mirror and `--preset` of both command lines."""
+    from rustracer_amd.raytracer import RenderQuality
+    assert RenderQuality.PRESETS == {"preview": (1, 1), "low": (4, 4), "medium": (16, 8), "high": (64, 16), "ultra": (256, 32)}
+    assert RenderQuality.NAMES["ultra"] == "Ultra (256 spp)"
+    with pytest.raises(ValueError):
+        RenderQuality.get("best")
     r = subprocess.run([EXE, "-i", "-w", "abc"], capture_output=True, text=True)
     assert r.returncode == 2 and "invalid value" in r.stderr
     r = subprocess.run([EXE, "-w", "10"], capture_output=True, text=True)      # no -i: the window is out of scope
@@ -68,6 +80,7 @@ def test_command_line_errors_and_help():
 @pytest.mark.parametrize("scene,args,okw", [
     ("teapot", ["-w", "64", "-h", "48", "-s", "3", "-l", "4", "-b", "5"], dict(width=64, height=48, spp=3, light_samples=4, bounces=5)),
     ("specular", ["-w", "40", "-h", "40"], dict(width=40, height=40, spp=4, light_samples=4, bounces=50)),     # defaults of src/main.rs:13-18
+    ("diffuse", ["-w", "36", "-h", "28", "-b", "3", "--preset", "medium"], dict(width=36, height=28, spp=16, light_samples=8, bounces=3)),   # gui.rs:56-74
     ("nonsense", ["-w", "32", "-h", "32", "-s", "2", "-b", "2", "--seed", "7"], dict(width=32, height=32, spp=2, light_samples=4, bounces=2, seed=7)),
 ])
 def test_image_mode_matches_oracle(gpu, teapot_obj, tmp_path, scene, args, okw):
@@ -93,12 +106,13 @@ def test_image_mode_as_one_rank_of_a_multi_gpu_job(gpu, teapot_obj, tmp_path):
     """One process per GPU (WORLD_SIZE / RANK / RT_COMM_ID_FILE): the binary makes the RCCL communicator from the id file, renders its
     shard, gathers over RCCL (rt_render_comm) and rank 0 writes the PNG.  Run here as a job of one rank: same image as without."""
     from oracle import binding as ob
-    env = dict(os.environ, SCENE="teapot", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", RT_COMM_ID_FILE=str(tmp_path / "rccl.id"))
+    env = dict(os.environ, SCENE="teapot", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", RT_COMM_ID_FILE=str(tmp_path / "rccl.id"), RT_JOB_ID="job-a")
+    (tmp_path / "rccl.id").write_bytes(b"\0" * 136)           # a file left by an earlier job: rank 0 replaces it, and removes its own once the communicator is up
     r = subprocess.run([EXE, "-i", "--obj-dir", os.path.dirname(teapot_obj), "-w", "70", "-h", "50", "-s", "2", "-l", "2", "-b", "3"], cwd=str(tmp_path), env=env,
                        capture_output=True, text=True, timeout=180)
     assert r.returncode == 0, r.stderr
     m = re.search(r"Saving with filename (\./dump/\d+\.png)", r.stdout)
-    assert m and os.path.getsize(tmp_path / "rccl.id") == 128
+    assert m and not os.path.exists(tmp_path / "rccl.id")
     img = read_png_rgb8(str(tmp_path / m.group(1)))
     ref = ob.OracleScene.named("teapot", teapot_obj).render(ob.make_params(width=70, height=50, spp=2, light_samples=2, bounces=3))["rgba"]
     assert np.array_equal(img, ref[:, :, :3])
