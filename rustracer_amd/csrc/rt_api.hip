@@ -154,7 +154,7 @@ struct rt_scene {
 
     bool opt_stats = false, opt_timing = false;
     uint64_t opt_max_paths = 1ull << 24;
-    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 16, opt_phase_bias = 16, opt_shadow_waves = 6, opt_light_waves = 4, opt_hot = 1, opt_extend_persist = 1, opt_extend_refill = 24, opt_extend_inner = 20, opt_extend_grid = 8, opt_lanes = 3, opt_shaft = 8;
+    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 16, opt_phase_bias = 16, opt_shadow_waves = 6, opt_light_waves = 4, opt_hot = 1, opt_extend_persist = 1, opt_extend_refill = 24, opt_extend_inner = 20, opt_extend_grid = 8, opt_lanes = 3, opt_shaft = 8, opt_graze_guard = 0;
     uint64_t opt_lane_min_pixels = 65536;
     uint64_t opt_fail_after_passes = 0;          // test hook: render_impl reports a failure once this many passes are enqueued (0 = never)
     uint32_t grid_max = 2048;
@@ -379,7 +379,9 @@ int upload_scene(rt_scene* s) {
         const uint32_t info = h.tri_mat[i] | (emissive ? 0u : RT_INFO_BLOCKER);
         tris[3 * (size_t)i] = make_float4(p1.x, p1.y, p1.z, bits_to_float(b.rank[i]));
         tris[3 * (size_t)i + 1] = make_float4(p2.x, p2.y, p2.z, bits_to_float(info));
-        tris[3 * (size_t)i + 2] = make_float4(p3.x, p3.y, p3.z, 0.0f);
+        const double e1l = sqrt(((double)p2.x - p1.x) * ((double)p2.x - p1.x) + ((double)p2.y - p1.y) * ((double)p2.y - p1.y) + ((double)p2.z - p1.z) * ((double)p2.z - p1.z));
+        const double e2l = sqrt(((double)p3.x - p1.x) * ((double)p3.x - p1.x) + ((double)p3.y - p1.y) * ((double)p3.y - p1.y) + ((double)p3.z - p1.z) * ((double)p3.z - p1.z));
+        tris[3 * (size_t)i + 2] = make_float4(p3.x, p3.y, p3.z, (float)(e1l * e2l * (1.0 / 1024.0)));   // grazes_triangle's threshold
         for (int k = 0; k < 3; ++k) nrm[3 * (size_t)i + k] = make_float4(n[3 * k], n[3 * k + 1], n[3 * k + 2], 0.0f);
     }
     for (uint32_t i = 0; i < S; ++i) {
@@ -591,6 +593,7 @@ int upload_scene(rt_scene* s) {
         }
     }
     d.n_wnodes = (s->wide.ok && s->opt_wide) ? s->wide.n_nodes() : 0u;
+    d.graze_guard = s->opt_graze_guard;
     d.refill_min = s->opt_refill_min; d.phase_bias = s->opt_phase_bias; d.extend_refill_min = s->opt_extend_refill; d.extend_inner_min = s->opt_extend_inner;
     if ((rc = s->w_stats.ensure(ST_COUNT))) return rc;
     HIP_TRY(hipMemset(s->w_stats.p, 0, ST_COUNT * sizeof(unsigned long long)));
@@ -1300,6 +1303,7 @@ int rt_set_option(rt_scene* s, const char* name, uint64_t value) {
     else if (n == "extend_refill") { s->opt_extend_refill = value > 64 ? 64 : (value < 1 ? 1 : (uint32_t)value); s->dev.extend_refill_min = s->opt_extend_refill; }
     else if (n == "extend_inner") { s->opt_extend_inner = value > 64 ? 64 : (uint32_t)value; s->dev.extend_inner_min = s->opt_extend_inner; }
     else if (n == "extend_grid") s->opt_extend_grid = value < 1 ? 1 : (uint32_t)value;
+    else if (n == "graze_guard") { s->opt_graze_guard = value ? 1 : 0; s->dev.graze_guard = s->opt_graze_guard; }
     else if (n == "fail_after_passes") s->opt_fail_after_passes = value;
     else if (n == "shaft") s->opt_shaft = value > RT_STACK_LDS ? RT_STACK_LDS : (uint32_t)value;
     else if (n == "inner_min") { s->opt_inner_min = value > 64 ? 64 : (uint32_t)value; s->dev.inner_min = s->opt_inner_min; }
@@ -1315,7 +1319,7 @@ int rt_get_option(const rt_scene* s, const char* name, uint64_t* value) {
         {"persist", s->opt_persist}, {"hot", s->opt_hot}, {"shadow_waves", s->opt_shadow_waves}, {"light_waves", s->opt_light_waves},
         {"refill_min", s->opt_refill_min}, {"phase_bias", s->opt_phase_bias}, {"inner_min", s->opt_inner_min}, {"lanes", s->opt_lanes},
         {"lane_min_pixels", s->opt_lane_min_pixels}, {"extend_persist", s->opt_extend_persist}, {"extend_refill", s->opt_extend_refill},
-        {"extend_inner", s->opt_extend_inner}, {"extend_grid", s->opt_extend_grid}, {"shaft", s->opt_shaft}};
+        {"extend_inner", s->opt_extend_inner}, {"extend_grid", s->opt_extend_grid}, {"shaft", s->opt_shaft}, {"graze_guard", s->opt_graze_guard}};
     for (const auto& e : table)
         if (n == e.name) { *value = e.v; return RT_OK; }
     return fail(RT_ERR_INVALID, "unknown option '" + n + "'");

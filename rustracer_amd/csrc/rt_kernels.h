@@ -44,7 +44,7 @@ namespace rt {
 
 struct DevScene {
     const float4* nodes;     // 4 x float4 per inner node (64 B)
-    const float4* tris;      // 3 x float4 per triangle (48 B): (p1, rank) (p2, info) (p3, 0)
+    const float4* tris;      // 3 x float4 per triangle (48 B): (p1, rank) (p2, info) (p3, 2^-10 |e1| |e2|: grazes_triangle)
     const float4* tri_nrm;   // 3 x float4 per triangle (48 B): vn1, vn2, vn3
     const float4* sph;       // (center, radius)
     const uint2* sph_aux;    // (rank, info)
@@ -64,6 +64,7 @@ struct DevScene {
     uint32_t extend_refill_min;   // k_extend_p: the same for closest-hit rays
     uint32_t extend_inner_min;    // k_extend_p: lanes at an inner node below which the wave turns to the waiting leaf tests (sc.inner_min of traverse())
     uint32_t phase_bias;     // k_trace_p: node step when 4 * lanes_at_nodes >= phase_bias * lanes_at_primitives
+    uint32_t graze_guard;    // Scene::intersect kernels: a ray that meets a triangle almost in its plane is searched unpruned from then on (1; 0 only for the tests)
 };
 
 // Occluder cache of k_light, passed by value as a kernel argument so that its fields arrive through scalar loads:
@@ -275,6 +276,12 @@ __device__ __forceinline__ bool hit_triangle_e(vec3 p1, vec3 e1, vec3 e2, vec3 o
     const vec3 s2 = cross3(s, e1);
     return hit_triangle_o(e1, e2, s, s2, dot3(s2, e2), d, t_out);
 }
+// Is the ray within about 2^-10 rad of the triangle's plane?  s1 . e1 = (d x e2) . e1 is the divisor of the test above; below 2^-10 |e1| |e2|
+// (`graze` = that product, stored with the triangle at upload: the third float4's w) its reciprocal has lost ten bits to cancellation and
+// the distance the test returns can be off by more than the pruning slack.  Same s1 and dot product as hit_triangle_e (the compiler shares them).
+__device__ __forceinline__ bool grazes_triangle(vec3 e1, vec3 e2, vec3 d, float graze) {
+    return !(fabsf(dot3(cross3(d, e2), e1)) >= graze);      // NaN counts as grazing
+}
 // Object::intersect, sphere arm (src/scene/objects.rs:58-76): the nearer root, negative included.
 __device__ __forceinline__ bool hit_sphere(float4 cr, vec3 o, vec3 d, float* t_out) {
     const vec3 l = sub(xyz(cr), o);
@@ -354,6 +361,7 @@ __device__ __forceinline__ void traverse(const DevScene& sc, bool have_ray, vec3
     const float lim_any = prune_limit(max_dist);
     uint32_t best_id = RT_MISS, best_rank = 0xFFFFFFFFu;
     bool occluded = false;
+    bool noprune = false;      // KIND 0: the ray has met a triangle almost in its plane (grazes_triangle): the rest of its search is the reference's, unpruned
     st.sp = 0;
     uint32_t cur = sc.root;
     bool done = !have_ray || (sc.n_tri + sc.n_sph == 0);
@@ -402,7 +410,7 @@ __device__ __forceinline__ void traverse(const DevScene& sc, bool have_ray, vec3
                 float tl, tr;
                 bool hl = slab(br, a.x, a.y, a.z, a.w, b.x, b.y, &tl);
                 bool hr = slab(br, b.z, b.w, c.x, c.y, c.z, c.w, &tr);
-                const float lim = KIND == 0 ? prune_limit(best) : lim_any;
+                const float lim = KIND == 0 ? (noprune ? __builtin_inff() : prune_limit(best)) : lim_any;
                 const uint32_t left = __float_as_uint(k.x), right = __float_as_uint(k.y), fragile = __float_as_uint(k.z);
                 hl = hl && (!(tl > lim) || (fragile & 1u));      // a subtree holding an ill-conditioned triangle is searched like the reference does: unpruned
                 hr = hr && (!(tr > lim) || (fragile & 2u));
@@ -432,6 +440,7 @@ __device__ __forceinline__ void traverse(const DevScene& sc, bool have_ray, vec3
                     const float4 A = tp[0], B = tp[1], C = tp[2];
                     if (STATS) ts->tris++;
                     ok = hit_triangle(xyz(A), xyz(B), xyz(C), o, d, &t);
+                    if (KIND == 0 && sc.graze_guard && grazes_triangle(sub(xyz(B), xyz(A)), sub(xyz(C), xyz(A)), d, C.w)) noprune = true;
                     rank = __float_as_uint(A.w);
                 } else {
                     if (STATS) ts->sphs++;
@@ -1002,7 +1011,7 @@ __global__ void __launch_bounds__(RT_BLOCK, 8) k_extend_p(DevScene sc, PassCtx p
     uint32_t next_row = __builtin_amdgcn_readfirstlane((blockIdx.x * RT_BLOCK + threadIdx.x) >> 6);   // rows of 64 rays: this wave's, then + n_waves
     uint32_t pend_at = 0u, pend_end = 0u;                                     // rays of the current row not yet handed out
     // the ray this lane is tracing (have)
-    bool have = false;
+    bool have = false, noprune = false;
     uint32_t e = 0u, cur = 0u, best_id = RT_MISS, best_rank = 0xFFFFFFFFu;
     float best = __builtin_inff();
     vec3 o = mk(0.0f, 0.0f, 0.0f), d = mk(0.0f, 0.0f, 1.0f);
@@ -1024,6 +1033,7 @@ __global__ void __launch_bounds__(RT_BLOCK, 8) k_extend_p(DevScene sc, PassCtx p
                 o = xyz(ro[e]); d = xyz(rd[e]);
                 br = make_box_ray(o, d);
                 best = __builtin_inff(); best_id = RT_MISS; best_rank = 0xFFFFFFFFu;
+                noprune = false;
                 st.sp = 0;
                 cur = sc.root;
                 have = true;
@@ -1046,7 +1056,7 @@ __global__ void __launch_bounds__(RT_BLOCK, 8) k_extend_p(DevScene sc, PassCtx p
                 float tl, tr;
                 bool hl = slab(br, a.x, a.y, a.z, a.w, b.x, b.y, &tl);
                 bool hr = slab(br, b.z, b.w, c.x, c.y, c.z, c.w, &tr);
-                const float lim = prune_limit(best);
+                const float lim = noprune ? __builtin_inff() : prune_limit(best);
                 const uint32_t left = __float_as_uint(k.x), right = __float_as_uint(k.y), fragile = __float_as_uint(k.z);
                 hl = hl && (!(tl > lim) || (fragile & 1u));
                 hr = hr && (!(tr > lim) || (fragile & 2u));
@@ -1075,6 +1085,7 @@ __global__ void __launch_bounds__(RT_BLOCK, 8) k_extend_p(DevScene sc, PassCtx p
                 const float4 A = tp[0], B = tp[1], C = tp[2];
                 if (STATS) tst.tris++;
                 ok = hit_triangle(xyz(A), xyz(B), xyz(C), o, d, &t);
+                if (sc.graze_guard && grazes_triangle(sub(xyz(B), xyz(A)), sub(xyz(C), xyz(A)), d, C.w)) noprune = true;
                 rank = __float_as_uint(A.w);
             } else {
                 if (STATS) tst.sphs++;

@@ -936,6 +936,112 @@ def test_pruned_closest_hit_equals_the_unpruned_search_on_slivers_and_grazing_ra
     assert (gi[:N] != 0xFFFFFFFF).mean() > 0.9 and len(np.unique(gi)) > 20000
 
 
+def _grazing_pairs(n_pairs, rays_per_pair, seed, theta_lo=-7.0, theta_hi=-3.0):
+    """The configuration in which distance pruning is weakest: a large, well-shaped triangle T met almost in its own plane (theta_lo ..
+    theta_hi decades of radians off it) by rays that hit a small triangle S first, S lying in front of the point where the ray enters T's
+    box.  The reference searches unpruned and takes whatever distance T's test returns (mod.rs:436-441), and at such angles 1 / (s1 . e1)
+    has few correct bits.  Every pair sits in a cell of its own, far from the others.  Returns (triangles, origins, directions), float32."""
+    rng = np.random.default_rng(seed)
+
+    def unit(v):
+        return v / np.linalg.norm(v, axis=1, keepdims=True)
+    P, R = n_pairs, rays_per_pair
+    cell = 4000.0
+    g = int(np.ceil(P ** (1 / 3)))
+    centre = np.stack(np.unravel_index(np.arange(P), (g, g, g)), axis=1).astype(np.float64) * cell
+    size = 10.0 ** rng.uniform(1, 2.7, P)                                  # T: side 10 .. 500, angles well away from 0
+    u = unit(rng.normal(size=(P, 3)))
+    v = unit(np.cross(u, rng.normal(size=(P, 3))))
+    a = centre + rng.uniform(-50, 50, (P, 3))
+    b = a + u * size[:, None]
+    c = a + (u * rng.uniform(0.2, 0.8, (P, 1)) + v * rng.uniform(0.5, 1.0, (P, 1))) * size[:, None]
+    nn = unit(np.cross(b - a, c - a))
+    # rays: towards a point q inside T, direction = in-plane direction tilted by theta out of the plane
+    pi = np.repeat(np.arange(P), R)
+    w = rng.dirichlet((1.5, 1.5, 1.5), P * R)
+    q = a[pi] * w[:, :1] + b[pi] * w[:, 1:2] + c[pi] * w[:, 2:]
+    phi = rng.uniform(0, 2 * np.pi, (P * R, 1))
+    inplane = u[pi] * np.cos(phi) + v[pi] * np.sin(phi)
+    theta = 10.0 ** rng.uniform(theta_lo, theta_hi, (P * R, 1)) * rng.choice([-1.0, 1.0], (P * R, 1))
+    d = unit(inplane * np.cos(theta) + nn[pi] * np.sin(theta))
+    dist = 10.0 ** rng.uniform(1.5, 3.0, (P * R, 1))
+    o = q - d * dist
+    # where the ray enters T's box (slab test in double), and S across the ray in front of that point: one S per pair, placed on the
+    # pair's first ray, large enough that the pair's other rays (which fan out from nearby origins) mostly hit it too
+    lo, hi = np.minimum(np.minimum(a, b), c)[pi], np.maximum(np.maximum(a, b), c)[pi]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t0, t1 = (lo - o) / d, (hi - o) / d
+    t_in = np.max(np.minimum(t0, t1), axis=1)
+    first = np.arange(P) * R
+    # all rays of a pair share the first ray's origin region: re-aim them from one origin so that one small S covers them
+    o = np.repeat(o[first], R, axis=0) + rng.normal(scale=1e-3, size=(P * R, 3))
+    d = unit(q - o)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t0, t1 = (lo - o) / d, (hi - o) / d
+    t_in = np.max(np.minimum(t0, t1), axis=1)
+    t_s = np.maximum(t_in[first], 1.0) * rng.uniform(0.2, 0.8, P)          # S in front of the box entry of the pair's first ray
+    mid = o[first] + d[first] * t_s[:, None]
+    e1 = unit(np.cross(d[first], rng.normal(size=(P, 3))))
+    e2 = unit(np.cross(d[first], e1))
+    half = (size * 1.5)[:, None] * (t_s / dist[first, 0])[:, None] + 0.05   # covers the fan of the pair's rays at that distance
+    s_tri = np.concatenate([mid - e1 * half - e2 * half, mid + e1 * 2 * half - e2 * half, mid - e1 * half + e2 * 2 * half], axis=1)
+    # three small decoys beside every T, off its plane (the rays never touch them): T then sits in a subtree of its own with them, and the search
+    # reaches that subtree's node only after it has found S, which is when its children's boxes are weighed against the best distance
+    cen = (a + b + c) / 3.0
+    decoys = []
+    for k in range(3):
+        dc = cen + nn * rng.uniform(6, 15, (P, 1)) * rng.choice([-1.0, 1.0], (P, 1)) + u * rng.uniform(-0.2, 0.2, (P, 1)) * size[:, None]
+        decoys.append(np.concatenate([dc, dc + u * 0.8, dc + v * 0.8], axis=1))
+    tri = np.concatenate([np.concatenate([a, b, c], axis=1), s_tri] + decoys).astype(np.float32)
+    return tri, o.astype(np.float32), unit(d).astype(np.float32)
+
+
+def test_pruning_differs_from_the_unpruned_search_only_where_the_reference_returns_noise(gpu):
+    """The dangerous configuration for distance pruning: 1,500 (far well-shaped triangle, nearer small triangle) pairs, the far
+    one in a subtree of its own, and a million rays that run within 1e-7 .. 1e-3 rad of the far triangle's plane and hit the near one first.
+    What the pruning rule guarantees, and what is held here: a ray on which the kernels and the reference's unpruned search disagree is a ray
+    for which the reference's own answer is arithmetic noise: the triangle it returns is not hit at all in exact arithmetic, or the distance
+    it returns for it is off from the true one by more than the pruning slack (2^-10 relative).  (Proof: the kernels skip a subtree only when
+    the ray enters its box beyond the best distance by more than the slack; a triangle in it that is truly hit is hit inside that box, so a
+    returned distance below the best one is short of the true one by more than the slack.)  Everywhere else ids and distances are bit-equal;
+    the disagreeing rays number a few in a million even here, where every ray is aimed to provoke them."""
+    from oracle import binding as ob
+    import rustracer_amd as ra
+    P = 1500
+    tri, org, d = _grazing_pairs(P, 700, seed=21)
+    nrm = np.tile(np.array([0, 0, 1, 0, 0, 1, 0, 0, 1], np.float32), (tri.shape[0], 1))
+    mats = np.zeros((1, 8), np.uint32)
+    mats[0, 1:4] = np.float32(0.5).view(np.uint32)
+    args = (tri, nrm, np.zeros(tri.shape[0], np.uint32), np.zeros((0, 4), np.float32), np.zeros(0, np.uint32), mats)
+    osc, gsc = ob.OracleScene.raw(*args), ra.Scene.from_arrays(*args)
+    gi, gt = gsc.intersect_rays(org, d)
+    oi, ot = _oracle_intersect_parallel(osc, org, d, workers=min(len(os.sched_getaffinity(0)), 16))
+    gsc.set_option("graze_guard", 1)       # the per-ray guard (off by default: DESIGN.md section 4): a ray that has met a triangle almost in its plane goes on unpruned
+    ui, ut = gsc.intersect_rays(org, d)
+    gsc.set_option("graze_guard", 0)
+    near_first = (oi >= P) & (oi < 2 * P)
+    bad = np.flatnonzero((gi != oi) | (gt.view(np.uint32) != ot.view(np.uint32)))
+    print("\nwinner: the near triangle %.3f, the far one %.3f, miss %.3f; rays that differ from the oracle: %d (%d with the per-ray guard)"
+          % (near_first.mean(), (oi < P).mean(), (oi == 0xFFFFFFFF).mean(), bad.size, int(((ui != oi) | (ut.view(np.uint32) != ot.view(np.uint32))).sum())))
+    assert near_first.mean() > 0.3 and (oi < P).mean() > 0.005
+    assert bad.size <= 20, "%d of %d rays differ" % (bad.size, org.shape[0])
+    assert int(((ui != oi) | (ut.view(np.uint32) != ot.view(np.uint32))).sum()) <= bad.size      # the guard never makes it worse
+    # every disagreement: the reference's winner, examined in double precision on the same float32 inputs
+    t64, o64, d64 = tri.astype(np.float64), org.astype(np.float64), d.astype(np.float64)
+    for r in bad:
+        assert oi[r] != 0xFFFFFFFF and gi[r] != 0xFFFFFFFF and ot[r] < gt[r], (r, gi[r], gt[r], oi[r], ot[r])    # the reference found something nearer than the kernels' hit
+        A, B, Cc = t64[oi[r], 0:3], t64[oi[r], 3:6], t64[oi[r], 6:9]
+        n = np.cross(B - A, Cc - A)
+        den = float(np.dot(n, d64[r]))
+        t_true = float(np.dot(n, A - o64[r])) / den if den != 0.0 else np.inf
+        hit = o64[r] + t_true * d64[r] - A
+        M = np.array([[np.dot(B - A, B - A), np.dot(B - A, Cc - A)], [np.dot(B - A, Cc - A), np.dot(Cc - A, Cc - A)]])
+        b1, b2 = np.linalg.solve(M, np.array([np.dot(hit, B - A), np.dot(hit, Cc - A)])) if np.isfinite(t_true) else (np.nan, np.nan)
+        inside = np.isfinite(t_true) and t_true > 0 and b1 >= 0 and b2 >= 0 and b1 + b2 <= 1
+        noise = (not inside) or abs(float(ot[r]) - t_true) > 0.9 * 2.0 ** -10 * abs(t_true)
+        assert noise, "ray %d: the reference's hit (%d, %r) is sound (true distance %r) and the kernels returned (%d, %r)" % (r, oi[r], ot[r], t_true, gi[r], gt[r])
+
+
 def test_native_rccl_gather_at_world_1(scenes):
     """The multi-GPU frame path (rt_comm_init_rank + rt_gather_tiles = pack -> ncclAllGather -> unpack, include/rustracer_hip.h) executed
     on this GPU with a one-rank communicator: RCCL initialises, the collective runs on the render stream, and the frame comes back as
@@ -968,7 +1074,54 @@ def test_native_rccl_gather_at_world_1(scenes):
         rgba = np.zeros((150, 200, 4), np.uint8)
         check(lib().rt_render_comm(gsc.handle, C.byref(p), comm._h, rgba.ctypes.data_as(C.c_void_p), None, None))
         assert np.array_equal(rgba, osc.render(op)["rgba"])
+        assert comm.last_gather_ms() > 0.0 and "RCCL" in comm.describe() and "librccl" in comm.describe()
     finally:
+        comm.destroy()
+
+
+@pytest.mark.parametrize("lanes", [1, 3])
+def test_a_failure_in_mid_frame_joins_the_lanes_and_still_enters_the_collective(scenes, lanes):
+    """Every exit of the render joins the lane streams back into the caller's stream, and a rank whose render fails still takes part in the
+    frame's collective (its peers would wait for ever otherwise) before it reports the error.  The failure is injected after N passes
+    ("fail_after_passes"): the call returns RT_ERR_HIP, the caller's stream and the communicator stay usable, and the next frame is right."""
+    import torch
+    from rustracer_amd import tiles
+    from rustracer_amd._lib import RT_ERR_HIP, RtError, check, lib
+    osc, gsc = scenes("dragon_small")
+    op = oracle_params(width=160, height=120, spp=6, light_samples=3, bounces=3, tile=(32, 32), shard=(0, 1), seed=77)
+    p = to_rt_params(op)
+    ref = osc.render(op)["rgba"]
+    comm = tiles.Comm(1, 0, lambda ident: ident)
+    gsc.set_option("lanes", lanes)
+    gsc.set_option("lane_min_pixels", 64)
+    gsc.set_option("max_paths", 160 * 120 // lanes)          # 6 passes per lane
+    try:
+        frame = torch.zeros((120, 160, 4), dtype=torch.uint8, device="cuda:0")
+        stream = torch.cuda.current_stream().cuda_stream
+        rgba = np.zeros((120, 160, 4), np.uint8)
+        for fail_at in (1, 2 * lanes):
+            gsc.set_option("fail_after_passes", fail_at)
+            rc = lib().rt_render_device(gsc.handle, C.byref(p), frame.data_ptr(), stream)
+            assert rc == RT_ERR_HIP and b"injected failure" in lib().rt_last_error()
+            torch.cuda.synchronize()                          # nothing is left running on a lane stream: the frame is the caller's again
+            probe = (frame.to(torch.int32).sum() >= 0).item()
+            assert probe
+            with pytest.raises(RtError) as ei:
+                check(lib().rt_render_comm(gsc.handle, C.byref(p), comm._h, rgba.ctypes.data_as(C.c_void_p), None, None))
+            assert ei.value.code == RT_ERR_HIP and "injected failure" in str(ei.value)
+            gather_after_failure = comm.last_gather_ms()
+            assert gather_after_failure > 0.0                 # the collective ran although the render had failed
+            gsc.set_option("fail_after_passes", 0)
+            check(lib().rt_render_comm(gsc.handle, C.byref(p), comm._h, rgba.ctypes.data_as(C.c_void_p), None, None))
+            assert np.array_equal(rgba, ref), (lanes, fail_at)
+            check(lib().rt_render_device(gsc.handle, C.byref(p), frame.data_ptr(), stream))
+            torch.cuda.synchronize()
+            assert np.array_equal(frame.cpu().numpy(), ref), (lanes, fail_at)
+    finally:
+        gsc.set_option("fail_after_passes", 0)
+        gsc.set_option("lanes", 3)
+        gsc.set_option("lane_min_pixels", 65536)
+        gsc.set_option("max_paths", 0)
         comm.destroy()
 
 
@@ -1080,3 +1233,28 @@ def test_device_built_trees_equal_the_host_built(gpu, teapot_obj, name):
     dn, dp = dev.wide_bvh()
     assert host.info.wide_depth == dev.info.wide_depth
     assert np.array_equal(hn, dn) and np.array_equal(hp.view(np.uint32), dp.view(np.uint32))
+    # ... and the GPU-built binary tree against the ORACLE's own recursive builder (oracle_rt.cpp, bvh 0.3.2 BVHNode::build restated), directly:
+    # every inner node's two child boxes and child references, in pre-order, and the leaf ranks = the reference's visiting order
+    from oracle import binding as ob
+    from test_host_scene import _oracle_inner_words
+    if name == "dragon_small":
+        osc = ob.OracleScene.dragon_mesh(*ra.dragon_standin_mesh(500, 100))
+    elif name == "dragon_full":
+        osc = ob.OracleScene.dragon_mesh(*ra.dragon_standin_mesh(*ra.DRAGON_STANDIN_FULL))
+    elif name == "chain":
+        e = dev.export()
+        osc = ob.OracleScene.raw(e["tri_pos"], e["tri_nrm"], e["tri_mat"], e["sph"], e["sph_mat"], e["mats"])
+    else:
+        osc = ob.OracleScene.named(name, teapot_obj)
+    ow = _oracle_inner_words(osc)
+    assert ow.shape == dw.shape and np.array_equal(ow[:, :14], dw[:, :14]), "GPU-built tree differs from the oracle's in %d node words" % int((ow[:, :14] != dw[:, :14]).sum())
+    order, stack = [], [int(dev.info.n_inner_nodes and 0)]
+    if dev.info.n_inner_nodes:
+        while stack:
+            ref = stack.pop()
+            if ref & 0x80000000:
+                order.append(ref & 0x7FFFFFFF)
+                continue
+            stack.append(int(ow[ref, 12]))          # left pushed, right pushed: right popped first (mod.rs:427-432)
+            stack.append(int(ow[ref, 13]))
+        assert np.array_equal(dr[np.array(order, np.int64)], np.arange(len(order), dtype=dr.dtype))
