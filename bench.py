@@ -231,9 +231,10 @@ def main():
                              "lanes_per_prim_step": round(ts["prim_lanes"] / max(ts["prim_steps"], 1), 1),
                              "lanes_per_refill": round(ts["refill_lanes"] / max(ts["refills"], 1), 1)}}
             # k_light, per light sample: the vertex record (position 16 B, normal 16 B, path slot 8 B, RNG state 8 B) is read once per
-            # vertex and serves nlL samples; every sample writes 1/64 of a row mask (8 B); a ray it cannot settle as blocked also writes
-            # its 32-B record (packed at the front of the row).
-            b_light = 48.0 / max(nlL, 1) + 8.0 / 64.0 + 32.0 * traced_frac
+            # vertex and serves nlL samples; every sample writes 1/64 of two row masks (2 x 8 B); a ray it cannot settle as blocked writes
+            # its 16-B record (direction, distance), and one that still has to be traced 16 B more (1/d of the box test, flags).
+            settled_frac = sc["shaft"][3] / n_shadow
+            b_light = 48.0 / max(nlL, 1) + 16.0 / 64.0 + 16.0 * (traced_frac + settled_frac) + 16.0 * traced_frac
             kernels["k_light"] = {
                 "what": "Object::sample_l for every (vertex, light sample) + the test of the object the ray starts on + the per-light occluder cache",
                 "unit": "light sample", "bytes_per_unit": round(b_light, 2), "units_per_launch": round(cnt["rays_shadow"] / launches, 1),
@@ -262,8 +263,8 @@ def main():
             "launches_per_step": int(cnt["launches_closest"]), "ms_per_step": round(cnt["kernel_ms_closest"], 2)}
         # The timed steps run `lanes` render lanes on streams of their own: kernels of different lanes overlap, so a
         # kernel's HIP-event duration in the timed region includes the time it shared the GPU, and the durations add up to more than the
-        # frame.  One more frame with a single lane gives every kernel's duration when it has the GPU to itself (`exclusive_*`).
-        ex = None
+        # frame.  One more frame with a single lane gives every kernel's duration when it has the GPU to itself: that is the duration the
+        # roofline figures use (`frac`), the overlapped one is reported beside it (`timed_region`).
         if lanes > 1:
             scene.set_option("lanes", 1)
             scene.set_option("timing", 1)
@@ -272,50 +273,63 @@ def main():
             ex = scene.counters()
             scene.set_option("timing", 0)
             scene.set_option("lanes", lanes)
-        ex_ms = {"k_trace_p": "kernel_ms_shadow", "k_shadow": "kernel_ms_shadow", "k_light": "kernel_ms_light", "k_extend_p": "kernel_ms_closest"}
+        else:
+            ex = cnt
+        ms_field = {"k_trace_p": "kernel_ms_shadow", "k_shadow": "kernel_ms_shadow", "k_light": "kernel_ms_light", "k_extend_p": "kernel_ms_closest"}
+        n_field = {"k_trace_p": "launches_shadow", "k_shadow": "launches_shadow", "k_light": "launches_shadow", "k_extend_p": "launches_closest"}
         frame_ms = cnt["kernel_ms_shadow"] + cnt["kernel_ms_light"] + cnt["kernel_ms_closest"] + cnt["kernel_ms_shade"]
-        pmc = pmc_kernels(a) if world == 1 else {}   # the committed counters are of the one-GPU launch sizes
+        ex_frame_ms = ex["kernel_ms_shadow"] + ex["kernel_ms_light"] + ex["kernel_ms_closest"] + ex["kernel_ms_shade"]
+        pmc = pmc_kernels(a) if world == 1 else {}   # per-unit counter figures of the newest committed profile of these kernel sources
+        mix = isa_mix()
         for name, k in kernels.items():
-            k["avg_launch_ms"] = round(k["ms_per_step"] / max(k["launches_per_step"], 1), 4)
-            k["share_of_kernel_time"] = round(k["ms_per_step"] / max(frame_ms, 1e-9), 4)
-            k["achieved_GBps"] = round(k["bytes_per_unit"] * k["units_per_launch"] / max(k["avg_launch_ms"], 1e-9) / 1e6, 2)
+            ex_launches = max(ex[n_field[name]], 1)
+            units_ex = k["units_per_launch"] * k["launches_per_step"] / ex_launches          # the same units in the one-lane frame's launches
+            k["timed_avg_launch_ms"] = round(k["ms_per_step"] / max(k["launches_per_step"], 1), 4)
+            k["avg_launch_ms"] = round(ex[ms_field[name]] / ex_launches, 4)
+            k["launches_one_lane"] = int(ex_launches)
+            k["units_per_launch_one_lane"] = round(units_ex, 1)
+            k["share_of_kernel_time"] = round(ex[ms_field[name]] / max(ex_frame_ms, 1e-9), 4)
+            k["achieved_GBps"] = round(k["bytes_per_unit"] * units_ex / max(k["avg_launch_ms"], 1e-9) / 1e6, 2)
             k["frac_of_hbm_peak"] = round(k["achieved_GBps"] / HBM_PEAK_GBS, 5)
-            if ex is not None:
-                k["exclusive_avg_launch_ms"] = round(ex[ex_ms[name]] / max(k["launches_per_step"], 1), 4)
-                k["exclusive_achieved_GBps"] = round(k["bytes_per_unit"] * k["units_per_launch"] / max(k["exclusive_avg_launch_ms"], 1e-9) / 1e6, 2)
+            k["timed_achieved_GBps"] = round(k["bytes_per_unit"] * k["units_per_launch"] / max(k["timed_avg_launch_ms"], 1e-9) / 1e6, 2)
             m = pmc.get(name, {}) if isinstance(pmc.get(name, {}), dict) else {}
-            k["traffic"] = m.get("hbm_bytes_per_launch")
-            for f in ("l2_hit_rate", "valu_issue_busy", "valu_active_lanes", "valu_insts_per_launch"):
+            # counters travel per unit (profiles/r*_pmc.json), so they describe THIS launch size whatever size they were profiled at
+            k["traffic"] = round(m["hbm_bytes_per_unit"] * units_ex) if "hbm_bytes_per_unit" in m else None
+            k["traffic_bytes_per_unit"] = m.get("hbm_bytes_per_unit")
+            for f in ("l2_hit_rate", "valu_issue_busy", "valu_active_lanes", "valu_insts_per_unit"):
                 if f in m:
                     k[f] = m[f]
-        dom = max(kernels, key=lambda n: kernels[n]["ms_per_step"])
+            mx = mix.get(name)
+            if mx and "valu_insts_per_unit" in m:
+                rate = m["valu_insts_per_unit"] * units_ex / max(k["avg_launch_ms"] * 1e-3, 1e-12)      # wave64 VALU instructions per second, whole chip
+                k["compute"] = {"bound": "valu_issue", "achieved": round(rate / 1e9, 2), "peak": round(mx["issue_peak_wave_instructions_per_s"] / 1e9, 2),
+                                "unit": "G wave64-instructions/s", "frac": round(rate / mx["issue_peak_wave_instructions_per_s"], 4),
+                                "mean_cycles_per_instruction": mx["mean_cycles_per_valu_instruction"], "mix": mx["mix"]}
+        dom = max(kernels, key=lambda n: kernels[n]["avg_launch_ms"] * kernels[n]["launches_one_lane"])
         d = kernels[dom]
         roofline = {
             "bound": "hbm", "achieved": d["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["frac_of_hbm_peak"],
             "traffic": d["traffic"], "traffic_source": pmc.get("_source"), "traffic_note": pmc.get("_note"),
-            "traffic_GBps": (round(d["traffic"] / max(d["avg_launch_ms"], 1e-9) / 1e6, 1) if d.get("traffic") else None),
             "kernel": "%s (%s)" % (dom, d["what"]), "bytes_per_unit": d["bytes_per_unit"], "unit_of_work": d["unit"],
-            "units_per_launch": d["units_per_launch"], "avg_launch_ms": d["avg_launch_ms"], "launches_per_step": d["launches_per_step"],
-            "render_lanes": lanes,
-            "exclusive": ({"avg_launch_ms": d["exclusive_avg_launch_ms"], "achieved": d["exclusive_achieved_GBps"],
-                           "frac": round(d["exclusive_achieved_GBps"] / HBM_PEAK_GBS, 5),
-                           "frame_ms_one_lane": round(ex["kernel_ms_shadow"] + ex["kernel_ms_light"] + ex["kernel_ms_closest"] + ex["kernel_ms_shade"], 2),
-                           "note": "the same kernel in a frame rendered with one lane (nothing else on the GPU); in the timed region %d lanes run "
-                                   "concurrently and a kernel's launch time includes the time it shared the GPU with the other lanes' kernels" % lanes}
-                          if ex is not None else None),
-            "limiter": {"kind": "VALU issue", "valu_issue_busy": d.get("valu_issue_busy"), "valu_active_lanes": d.get("valu_active_lanes"),
-                        "valu_insts_per_launch": d.get("valu_insts_per_launch"),
-                        "note": "valu_issue_busy = fraction of all SIMD cycles of the kernel's run time with a VALU instruction executing "
-                                "(rocprofv3 --pmc SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE; profiles/); at ~1.0 the kernel is bound by instruction "
-                                "issue, not by HBM, so frac is low by construction (SURVEY.md §8d)"},
+            "units_per_launch": d["units_per_launch_one_lane"], "avg_launch_ms": d["avg_launch_ms"], "launches_per_step": d["launches_one_lane"],
+            "definition": "achieved = bytes_per_unit x units_per_launch / avg_launch_ms of the dominant kernel (largest share of the frame's kernel time), the "
+                          "launch time being the HIP-event mean over a frame rendered with ONE lane, i.e. with the GPU to itself; traffic = L2<->fabric bytes "
+                          "per launch = hbm_bytes_per_unit (FETCH_SIZE x 2 + WRITE_SIZE of separate --pmc passes, per unit) x units_per_launch",
+            "timed_region": {"render_lanes": lanes, "avg_launch_ms": d["timed_avg_launch_ms"], "units_per_launch": d["units_per_launch"],
+                             "launches_per_step": d["launches_per_step"], "achieved": d["timed_achieved_GBps"],
+                             "frac": round(d["timed_achieved_GBps"] / HBM_PEAK_GBS, 5), "kernel_ms_sum": round(frame_ms, 2), "ms_per_step": round(ms_per_step, 3),
+                             "note": "in the timed steps %d lanes run concurrently: a kernel's HIP-event duration includes the time it shared the GPU with the "
+                                     "other lanes' kernels, and the durations sum to more than the step" % lanes},
+            "frame_ms_one_lane": round(ex_frame_ms, 2),
+            "compute": d.get("compute"),
+            "compute_note": "the kernel is bound by VALU instruction issue, not by HBM: `compute` sets its measured wave64 VALU instruction rate (SQ_INSTS_VALU "
+                            "per unit from the PMC passes x units / launch time) against the issue ceiling of its instruction mix (profiles/r*_isa_mix.json: "
+                            "static class mix of its loop x the per-class issue cost measured by tools/valu_rate.hip, profiles/r02_valu_rate.txt)",
             "kernels": kernels,
-            "kernel_ms_per_step": {"k_light": round(cnt["kernel_ms_light"], 2), "k_trace_p": round(cnt["kernel_ms_shadow"], 2),
-                                   "k_extend+k_extend_p": round(cnt["kernel_ms_closest"], 2), "shade+generate+resolve+k_binary": round(cnt["kernel_ms_shade"], 2)},
-            "note": "achieved = algorithmic bytes per launch / HIP-event launch time of the dominant kernel (the kernel with the largest share of "
-                    "the frame; k_light and k_trace_p are within a few percent of each other, see `kernels`).  The scene (%.0f MB) is resident in L2 / "
-                    "Infinity Cache: most algorithmic bytes (BVH nodes, primitive records) are served on-die, so `achieved` can exceed what HBM "
-                    "delivers; `traffic` / `traffic_GBps` are the L2<->fabric bytes per launch measured with the TCC counters.  Every kernel that "
-                    "matters is bound by VALU instruction issue (`limiter`), not by memory" % (scene.info.device_bytes / 1e6),
+            "kernel_ms_per_step_one_lane": {"k_light": round(ex["kernel_ms_light"], 2), "k_trace_p": round(ex["kernel_ms_shadow"], 2),
+                                            "k_extend+k_extend_p": round(ex["kernel_ms_closest"], 2), "shade+generate+resolve+k_binary": round(ex["kernel_ms_shade"], 2)},
+            "note": "The scene (%.0f MB) is resident in L2 / Infinity Cache: most algorithmic bytes of the traversal kernels (BVH nodes, primitive records) are "
+                    "served on-die, so their `achieved` can exceed what HBM delivers; `traffic` is what crossed the fabric" % (scene.info.device_bytes / 1e6),
         }
 
     # ---- CPU baseline: the oracle (reference algorithm, unpruned traversal, recursive integrator) on a bounded sample ----
@@ -330,7 +344,8 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[3]: dragon GI, %dx%d, %d spp, %d light samples, depth %d, 32x32 screen tiles over %d GPU(s)%s"
                    % (a.width, a.height, a.spp, a.light_samples, a.bounces, world, (" + native RCCL all-gather (rt_gather_tiles)" if comm is not None or world == 1 else " + gloo all_gather through the host") if world > 1 else ""),
-                   "mesh": "%s, %d triangles" % (mesh_label, n_tri - 10), "seed": a.seed, "scene_build_s": round(scene_s, 2), "render_lanes": lanes},
+                   "mesh": "%s, %d triangles" % (mesh_label, n_tri - 10), "seed": a.seed, "scene_build_s": round(scene_s, 2), "render_lanes": lanes,
+                   "spp": a.spp, "max_paths": scene.get_option("max_paths")},
         "samples_per_s": round(samples * a.steps / elapsed, 1),
         "rays_per_step": int(rays_per_step), "rays_closest_per_step": int(rays_closest), "rays_shadow_per_step": int(rays_shadow),
         "rays_per_sample": round(rays_per_step / max(samples, 1), 2),
@@ -376,6 +391,21 @@ def launch_ranks(n):
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     proc = subprocess.run(cmd, env=env)
     raise SystemExit(proc.returncode)
+
+
+def isa_mix():
+    """Issue-class mix of the kernels' loops (profiles/r*_isa_mix.json, tools/isa_mix.py), only when it was made from the sources that run."""
+    import glob
+    from rustracer_amd._lib import kernel_source_hash
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_isa_mix.json")))
+    if not paths:
+        return {}
+    try:
+        with open(paths[-1]) as f:
+            j = json.load(f)
+    except (OSError, ValueError):
+        return {}
+    return j.get("kernels", {}) if j.get("kernel_source_hash") == kernel_source_hash() else {}
 
 
 def pmc_kernels(a):

@@ -9,6 +9,9 @@ mkdir -p $R/$OUT
 python3 -c "import sys; sys.path.insert(0, '$R'); from rustracer_amd._lib import kernel_source_hash as h; print(h())" > $R/$OUT/source_hash.txt
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 1 --warmup 1 --cpu-seconds 0 --stats-spp 0 $@"
+# the same workload once without the profiler but with the instrumented pass: its line carries the units (light samples, traced rays, intersect
+# rays) each kernel processes per launch, which turn the per-launch counters below into per-unit figures
+timeout -k 10 300 python3 $R/bench.py --steps 1 --warmup 1 --cpu-seconds 0 --stats-spp 2 "$@" > $R/$OUT/units.log 2>&1 || { tail -5 $R/$OUT/units.log; exit 1; }
 PASSES=${PASSES:-"trace sq1 sq2 tcc fetch write tcp"}
 declare -A PMC
 PMC[sq1]="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY"

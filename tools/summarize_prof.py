@@ -136,14 +136,32 @@ def write_pmc_json(agg, calls, src, path, workload):
             e["valu_issue_busy"] = round(valu_busy(a), 4)
             e["valu_active_lanes"] = round(a.get("SQ_THREAD_CYCLES_VALU", 0) / max(64.0 * a["SQ_ACTIVE_INST_VALU"], 1), 4)
             e["valu_insts_per_launch"] = round(a.get("SQ_INSTS_VALU", 0) / max(calls[k].get("SQ_INSTS_VALU", 1), 1))
-    for e in kernels.values():
+    # units per launch of the profiled workload (units.log: the same bench command with its instrumented pass), so that the figures travel per
+    # UNIT (light sample, traced ray, intersect ray) and bench.py can scale them to the launch sizes of the run it reports
+    units, run_cfg = {}, {}
+    upath = os.path.join(src, "units.log")
+    if os.path.exists(upath):
+        for line in open(upath):
+            if line.startswith("{"):
+                b = json.loads(line)
+                for kn, kv in ((b.get("roofline") or {}).get("kernels") or {}).items():
+                    units[kn] = (kv["units_per_launch"], kv["unit"])
+                run_cfg = {"spp": (b.get("config") or {}).get("spp"), "render_lanes": (b.get("config") or {}).get("render_lanes"), "max_paths": (b.get("config") or {}).get("max_paths")}
+    for name, e in kernels.items():
         e["hbm_bytes_per_launch"] = round(e["fetch_bytes_per_launch"] + e["write_bytes_per_launch"])
         e["fetch_bytes_per_launch"] = round(e["fetch_bytes_per_launch"])
         e["write_bytes_per_launch"] = round(e["write_bytes_per_launch"])
+        if name in units and units[name][0] > 0:
+            u = units[name][0]
+            e["unit"] = units[name][1]
+            e["units_per_launch_profiled"] = u
+            e["hbm_bytes_per_unit"] = round(e["hbm_bytes_per_launch"] / u, 4)
+            if "valu_insts_per_launch" in e:
+                e["valu_insts_per_unit"] = round(e["valu_insts_per_launch"] / u, 5)      # wave64 instructions (SQ_INSTS_VALU) per unit
     j = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of tools/profile.sh, %s" % os.path.basename(src.rstrip("/")),
          "correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950 counts 128-B requests as 64 B) + WRITE_SIZE KiB x 1024, averaged over the kernel's dispatches",
          "valu": "valu_issue_busy = 4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs); valu_active_lanes = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)",
-         "workload": workload, "kernels": kernels,
+         "workload": workload, "profiled_run": run_cfg, "kernels": kernels,
          "kernel_source_hash": (open(os.path.join(src, "source_hash.txt")).read().strip() if os.path.exists(os.path.join(src, "source_hash.txt")) else None),
          "git_commit": os.popen("git -C %s rev-parse --short HEAD 2>/dev/null" % os.path.dirname(os.path.abspath(__file__))).read().strip() or None}
     open(path, "w").write(json.dumps(j, indent=1) + "\n")
