@@ -152,7 +152,9 @@ int rt_cast_primary_device(rt_scene* scene, const rt_render_params* params, void
  * must already be resident on the GPU (uploading allocates: one earlier rt_cast_primary_device / rt_render_device call does
  * it), and its BVH may need at most 32 traversal-stack entries per ray (16 in LDS + 16 rows of the static array; the
  * 871,200-triangle stand-in needs 27).  The grid is capped at 1024 workgroups.  Every call on a GPU shares that GPU's
- * array: calls that overlap in time on one GPU (two streams, two threads) race; calls on one stream do not. */
+ * array: calls that overlap in time on one GPU (two streams, two threads) race; calls on one stream do not.  The counters of the call
+ * live in that array too: rt_get_counters on this scene returns them until another scene makes a no-alloc call on the same GPU, and
+ * reports RT_ERR_INVALID afterwards instead of the other scene's numbers. */
 int rt_cast_primary_noalloc(rt_scene* scene, const rt_render_params* params, void* ids_dev, void* t_dev, void* stream);
 
 /* Arbitrary rays (host arrays, 3 floats each): Scene::intersect and Scene::is_occluded. */

@@ -154,7 +154,7 @@ struct rt_scene {
 
     bool opt_stats = false, opt_timing = false;
     uint64_t opt_max_paths = 1ull << 24;
-    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 16, opt_phase_bias = 16, opt_shadow_waves = 6, opt_light_waves = 4, opt_hot = 1, opt_extend_persist = 1, opt_extend_refill = 24, opt_extend_inner = 20, opt_extend_grid = 8, opt_lanes = 3, opt_shaft = 8, opt_graze_guard = 0;
+    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 16, opt_phase_bias = 16, opt_shadow_waves = 6, opt_light_waves = 4, opt_hot = 1, opt_extend_persist = 1, opt_extend_refill = 24, opt_extend_inner = 20, opt_extend_grid = 8, opt_lanes = 3, opt_shaft = 8, opt_graze_guard = 0, opt_trace_grid = 8;
     uint64_t opt_lane_min_pixels = 65536;
     uint64_t opt_fail_after_passes = 0;          // test hook: render_impl reports a failure once this many passes are enqueued (0 = never)
     uint32_t grid_max = 2048;
@@ -904,10 +904,16 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
                         else hipLaunchKernelGGL(k_binary<false>, dim3(64), dim3(RT_BLOCK), 0, st, dv, pc, level);
                         end_timing(s, st, ev);
                         begin_timing(s, st, 1, &ev);
-                        if (s->opt_stats) hipLaunchKernelGGL((k_trace_p<true, 8>), dim3(gs), dim3(RT_BLOCK), 0, st, dv, pc, level);
-                        else if (s->opt_shadow_waves >= 8) hipLaunchKernelGGL((k_trace_p<false, 8>), dim3(gs), dim3(RT_BLOCK), 0, st, dv, pc, level);
-                        else if (s->opt_shadow_waves >= 6) hipLaunchKernelGGL((k_trace_p<false, 6>), dim3(gs), dim3(RT_BLOCK), 0, st, dv, pc, level);
-                        else hipLaunchKernelGGL((k_trace_p<false, 5>), dim3(gs), dim3(RT_BLOCK), 0, st, dv, pc, level);
+                        // a persistent kernel: no more workgroups than are resident at once (waves per SIMD of the variant = workgroups per CU),
+                        // or the ones that start late run on a third of the chip (2.7 of 6 waves resident with grid_max: profiles/r03b)
+                        const uint32_t tw = s->opt_stats ? 8u : (s->opt_shadow_waves >= 8 ? 8u : (s->opt_shadow_waves >= 6 ? 6u : 5u));
+                        uint32_t gt = s->grid_max / 8u * tw * s->opt_trace_grid / 8u;
+                        if (gt > gs) gt = gs;
+                        if (gt < 1u) gt = 1u;
+                        if (s->opt_stats) hipLaunchKernelGGL((k_trace_p<true, 8>), dim3(gt), dim3(RT_BLOCK), 0, st, dv, pc, level);
+                        else if (tw == 8u) hipLaunchKernelGGL((k_trace_p<false, 8>), dim3(gt), dim3(RT_BLOCK), 0, st, dv, pc, level);
+                        else if (tw == 6u) hipLaunchKernelGGL((k_trace_p<false, 6>), dim3(gt), dim3(RT_BLOCK), 0, st, dv, pc, level);
+                        else hipLaunchKernelGGL((k_trace_p<false, 5>), dim3(gt), dim3(RT_BLOCK), 0, st, dv, pc, level);
                     } else if (hemi) {
                         if (s->opt_stats) hipLaunchKernelGGL((k_shadow<true, true>), dim3(gs), dim3(RT_BLOCK), 0, st, dv, pc, level);
                         else hipLaunchKernelGGL((k_shadow<false, true>), dim3(gs), dim3(RT_BLOCK), 0, st, dv, pc, level);
@@ -1303,6 +1309,7 @@ int rt_set_option(rt_scene* s, const char* name, uint64_t value) {
     else if (n == "extend_refill") { s->opt_extend_refill = value > 64 ? 64 : (value < 1 ? 1 : (uint32_t)value); s->dev.extend_refill_min = s->opt_extend_refill; }
     else if (n == "extend_inner") { s->opt_extend_inner = value > 64 ? 64 : (uint32_t)value; s->dev.extend_inner_min = s->opt_extend_inner; }
     else if (n == "extend_grid") s->opt_extend_grid = value < 1 ? 1 : (uint32_t)value;
+    else if (n == "trace_grid") s->opt_trace_grid = value < 1 ? 1 : (uint32_t)value;
     else if (n == "graze_guard") { s->opt_graze_guard = value ? 1 : 0; s->dev.graze_guard = s->opt_graze_guard; }
     else if (n == "fail_after_passes") s->opt_fail_after_passes = value;
     else if (n == "shaft") s->opt_shaft = value > RT_STACK_LDS ? RT_STACK_LDS : (uint32_t)value;
@@ -1319,7 +1326,7 @@ int rt_get_option(const rt_scene* s, const char* name, uint64_t* value) {
         {"persist", s->opt_persist}, {"hot", s->opt_hot}, {"shadow_waves", s->opt_shadow_waves}, {"light_waves", s->opt_light_waves},
         {"refill_min", s->opt_refill_min}, {"phase_bias", s->opt_phase_bias}, {"inner_min", s->opt_inner_min}, {"lanes", s->opt_lanes},
         {"lane_min_pixels", s->opt_lane_min_pixels}, {"extend_persist", s->opt_extend_persist}, {"extend_refill", s->opt_extend_refill},
-        {"extend_inner", s->opt_extend_inner}, {"extend_grid", s->opt_extend_grid}, {"shaft", s->opt_shaft}, {"graze_guard", s->opt_graze_guard}};
+        {"extend_inner", s->opt_extend_inner}, {"extend_grid", s->opt_extend_grid}, {"shaft", s->opt_shaft}, {"trace_grid", s->opt_trace_grid}, {"graze_guard", s->opt_graze_guard}};
     for (const auto& e : table)
         if (n == e.name) { *value = e.v; return RT_OK; }
     return fail(RT_ERR_INVALID, "unknown option '" + n + "'");

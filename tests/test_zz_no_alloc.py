@@ -9,12 +9,16 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _cast(fn, scene, p, torch):
+def _cast(fn, scene, p, torch, must_not_allocate=False):
     from rustracer_amd._lib import check
     ids = torch.full((p.height, p.width), 0x7FFFFFFF, dtype=torch.int32, device="cuda:0")
     ts = torch.full((p.height, p.width), -1.0, dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]              # hipMemGetInfo: any hipMalloc / hipFree inside the call would move it
     check(fn(scene.handle, C.byref(p), ids.data_ptr(), ts.data_ptr(), torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
+    if must_not_allocate:
+        assert torch.cuda.mem_get_info()[0] == free_before, "the no-alloc entry point changed the device's free memory"
     cnt = scene.counters()
     return ids.cpu().numpy().view(np.uint32), ts.cpu().numpy(), cnt
 
@@ -58,7 +62,7 @@ def test_no_alloc_cast_equals_device_cast(gpu, which):
     for w, h, shard in ((1280, 720, (0, 1)), (333, 177, (0, 1)), (640, 360, (1, 3))):   # second and third inputs are smaller
         p = params(w, h, shard)
         ref_ids, ref_t, ref_cnt = _cast(L.rt_cast_primary_device, scene, p, torch)
-        got_ids, got_t, got_cnt = _cast(L.rt_cast_primary_noalloc, scene, p, torch)
+        got_ids, got_t, got_cnt = _cast(L.rt_cast_primary_noalloc, scene, p, torch, must_not_allocate=True)
         assert np.array_equal(got_ids, ref_ids), "%d ids differ at %dx%d" % (int((got_ids != ref_ids).sum()), w, h)
         assert np.array_equal(got_t.view(np.uint32), ref_t.view(np.uint32))
         for k in ("rays_closest", "samples", "closest_inner", "closest_tris", "closest_sphs"):
@@ -68,8 +72,32 @@ def test_no_alloc_cast_equals_device_cast(gpu, which):
     scene.set_option("stats", 0)
     p = params(200, 120)
     ref_ids, ref_t, _ = _cast(L.rt_cast_primary_device, scene, p, torch)
-    got_ids, got_t, _ = _cast(L.rt_cast_primary_noalloc, scene, p, torch)
+    got_ids, got_t, _ = _cast(L.rt_cast_primary_noalloc, scene, p, torch, must_not_allocate=True)
     assert np.array_equal(got_ids, ref_ids) and np.array_equal(got_t.view(np.uint32), ref_t.view(np.uint32))
+    # what the entry point exists for: it can be recorded into a HIP graph (stream capture forbids hipMalloc / hipFree and every
+    # synchronising call), and the replayed graph gives the same ids and distances
+    from rustracer_amd._lib import check
+    ids = torch.full((p.height, p.width), 0x7FFFFFFF, dtype=torch.int32, device="cuda:0")
+    ts = torch.full((p.height, p.width), -1.0, dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        check(L.rt_cast_primary_noalloc(scene.handle, C.byref(p), ids.data_ptr(), ts.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    ids.fill_(0x7FFFFFFF)
+    ts.fill_(-1.0)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(ids.cpu().numpy().view(np.uint32), ref_ids) and np.array_equal(ts.cpu().numpy().view(np.uint32), ref_t.view(np.uint32))
+    # the counters live in the GPU's shared scratch: once another scene has made a no-alloc call there, this scene's are gone and say so
+    other = _chain_scene(20, 2.0, 1e-3)
+    q = params(64, 64)
+    _cast(L.rt_cast_primary_device, other, q, torch)
+    _cast(L.rt_cast_primary_noalloc, scene, p, torch)
+    assert scene.counters()["samples"] == p.width * p.height
+    _cast(L.rt_cast_primary_noalloc, other, q, torch)
+    with pytest.raises(RtError):
+        scene.counters()
+    assert other.counters()["samples"] == 64 * 64
 
 
 def test_no_alloc_rejects_a_tree_deeper_than_its_scratch(gpu):

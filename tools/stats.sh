@@ -7,7 +7,7 @@ for o in "$@"; do
 import sys,json
 d=json.loads(sys.stdin.read()); r=d['roofline']; k=r['kernels']
 print('Mrays/s', d['value'], 'ms/step', d['ms_per_step'], 'lanes-overlapped kernel ms', d['kernel_ms_last_step'])
-print('one-lane frame ms', (r.get('exclusive') or {}).get('frame_ms_one_lane'), {n: (v.get('exclusive_avg_launch_ms'), v['launches_per_step']) for n, v in k.items()})
+print('one-lane frame ms', r.get('frame_ms_one_lane'), {n: (v.get('avg_launch_ms'), v.get('launches_one_lane')) for n, v in k.items()}, 'compute', r.get('compute'))
 print('trace per_unit', k.get('k_trace_p', {}).get('per_unit'))
 print('shaft', k.get('k_light', {}).get('shaft'))
 " || exit 1
