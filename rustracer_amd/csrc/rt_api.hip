@@ -153,7 +153,7 @@ struct rt_scene {
     DevBuf<float> w_rays;   // scratch for arbitrary-ray calls
 
     bool opt_stats = false, opt_timing = false;
-    uint64_t opt_max_paths = 1ull << 24;
+    uint64_t opt_max_paths = 1ull << 25;
     uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 16, opt_phase_bias = 16, opt_shadow_waves = 6, opt_light_waves = 4, opt_hot = 1, opt_extend_persist = 1, opt_extend_refill = 24, opt_extend_inner = 20, opt_extend_grid = 8, opt_lanes = 3, opt_shaft = 8, opt_graze_guard = 0, opt_trace_grid = 8;
     uint64_t opt_lane_min_pixels = 65536;
     uint64_t opt_fail_after_passes = 0;          // test hook: render_impl reports a failure once this many passes are enqueued (0 = never)
@@ -1294,7 +1294,7 @@ int rt_set_option(rt_scene* s, const char* name, uint64_t value) {
     const std::string n(name);
     if (n == "stats") s->opt_stats = value != 0;
     else if (n == "timing") s->opt_timing = value != 0;
-    else if (n == "max_paths") s->opt_max_paths = value ? value : (1ull << 24);
+    else if (n == "max_paths") s->opt_max_paths = value ? value : (1ull << 25);
     else if (n == "self_test") { s->opt_self_test = value ? 1 : 0; s->dev.self_test = s->opt_self_test; }
     else if (n == "wide") { s->opt_wide = value ? 1 : 0; s->dev.n_wnodes = (s->wide.ok && s->opt_wide) ? s->wide.n_nodes() : 0u; }
     else if (n == "persist") s->opt_persist = value ? 1 : 0;

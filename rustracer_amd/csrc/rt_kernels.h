@@ -169,6 +169,7 @@ __device__ __forceinline__ vec3 screen_to_world(const rt_render_params& P, uint3
 //             s + 1 ulp if x - (s + 1ulp) s > 0.  Checked exhaustively.
 // (mid_range, div_range, rcp_mid, div_mid, sqrt_mid: rt_math.h, where acos_s uses them too)
 __device__ __forceinline__ bool in_2pm20(float x) { const float a = fabsf(x); return a >= 0x1p-20f && a <= 0x1p+20f; }
+__device__ __forceinline__ bool in_2pm18_20(float x) { const float a = fabsf(x); return a >= 0x1p-18f && a <= 0x1p+20f; }
 __device__ __forceinline__ float rcp_ieee(float x) {          // == 1.0f / x
     if (mid_range(x)) return rcp_mid(x);
     return 1.0f / x;
@@ -1332,6 +1333,7 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
         const vec3 own_e1 = sub(xyz(B), xyz(A)), own_e2 = sub(xyz(C), xyz(A)), own_s = sub(p, xyz(A));
         const vec3 own_s2 = cross3(own_s, own_e1);
         const float own_tn = dot3(own_s2, own_e2);
+        const bool p_wide_ok = fabsf(p.x) <= WIDE_COORD_MAX && fabsf(p.y) <= WIDE_COORD_MAX && fabsf(p.z) <= WIDE_COORD_MAX;
         uint64_t rng = rng0;                                                   // the vertex's stream: two draws per light sample, in sample order
         size_t row = ls_slot(e0 & ~63u, 0, nlL);                               // first slot of the row of (this tile, sample j): + 64 per sample
         unsigned long long* row_mask = pc.tmask + (size_t)(e0 >> 6) * nlL;    // mask of that row: + 1 per sample
@@ -1385,7 +1387,8 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
             float d_s;
             vec3 wi;
             BoxRay br;
-            if (in_2pm20(ps.x) & in_2pm20(ps.y) & in_2pm20(ps.z)) {
+            bool binary;
+            if (in_2pm18_20(ps.x) & in_2pm18_20(ps.y) & in_2pm18_20(ps.z)) {
                 d_s = sqrt_mid(dot3(ps, ps));
                 wi = scale(ps, rcp_mid(d_s));
                 const float n = sqrt_mid(dot3(wi, wi)), y = rcp_mid(n);
@@ -1393,13 +1396,16 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
                 br.ox = p.x; br.oy = p.y; br.oz = p.z;
                 br.ix = rcp_mid(u.x); br.iy = rcp_mid(u.y); br.iz = rcp_mid(u.z);
                 br.sx = u.x < 0.0f; br.sy = u.y < 0.0f; br.sz = u.z < 0.0f;
+                // every |u| component is at least 2^-18 / (sqrt(3) 2^20) (1 - 2^-20) > 2^-39, so |1/u| < 2^40: the ray is fit for the 8-wide tree
+                // (wide_ray_ok) as far as its direction goes; the origin's part of that test is the vertex's (p_wide_ok)
+                binary = !p_wide_ok;
             } else {
                 d_s = sqrt_ieee(dot3(ps, ps));
                 wi = scale(ps, rcp_ieee(d_s));
                 br = make_box_ray(p, wi);
+                binary = !wide_ray_ok(br, p);
             }
             bool blocked = false;
-            const bool binary = !wide_ray_ok(br, p);
             if (!binary && (self_is_tri || self_is_sph) && slab_rel(br, own_dnx, own_dny, own_dnz, own_dxx, own_dxy, own_dxz)) {
                 float t = 0.0f;
                 bool ok;
