@@ -56,6 +56,7 @@ int fail(int code, const std::string& msg) {
 static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_BYTES];
 static_assert(ST_COUNT * sizeof(unsigned long long) <= 256, "the counters must fit the first 256 bytes of the scratch");
 void* g_scratch_ptr[RT_MAX_DEVICES];   // device address of `scratch` on each GPU this process has asked for (nullptr: not yet)
+const void* g_scratch_owner[RT_MAX_DEVICES];   // the scene whose rt_cast_primary_noalloc call wrote the counters in that GPU's scratch last
 
 // Device address of this GPU's copy of `scratch`; `device` must be the current device.
 int scratch_for(int device, void** out) {
@@ -1053,6 +1054,7 @@ int rt_scene_create(const float* tri_pos, const float* tri_nrm, const uint32_t* 
 
 void rt_scene_destroy(rt_scene* s) {
     if (!s) return;
+    if (s->device >= 0 && s->device < RT_MAX_DEVICES && g_scratch_owner[s->device] == s) g_scratch_owner[s->device] = nullptr;
     (void)hipSetDevice(s->device);
     if (s->uploaded) (void)hipDeviceSynchronize();
     s->d_nodes.release(); s->d_tris.release(); s->d_tri_nrm.release(); s->d_sph.release(); s->d_mats.release();
@@ -1190,6 +1192,7 @@ int rt_cast_primary_noalloc(rt_scene* s, const rt_render_params* params, void* i
     s->launches[0] = 1; s->launches[1] = s->launches[2] = s->launches[3] = 0;
     s->samples = 0;
     s->stats_src = (const unsigned long long*)ptr;
+    if (s->device >= 0 && s->device < RT_MAX_DEVICES) g_scratch_owner[s->device] = s;
     // the counters start at zero; the overflow rows are written before they are read
     HIP_TRY(hipMemsetAsync(ptr, 0, 256, stream));
     if (sh.n_own_pix == 0) return RT_OK;
@@ -1268,6 +1271,8 @@ int rt_get_counters(const rt_scene* cs, rt_counters* out) {
     BIND(s->device);
     HIP_TRY(hipDeviceSynchronize());
     unsigned long long st[ST_COUNT];
+    if (s->stats_src && s->stats_src != s->w_stats.p && s->device >= 0 && s->device < RT_MAX_DEVICES && g_scratch_owner[s->device] != s)
+        return fail(RT_ERR_INVALID, "the counters of this scene's last call (rt_cast_primary_noalloc) lived in the GPU's shared scratch, and another scene's call has overwritten them since");
     HIP_TRY(hipMemcpy(st, s->stats_src ? s->stats_src : s->w_stats.p, sizeof st, hipMemcpyDeviceToHost));
     memset(out, 0, sizeof *out);
     out->rays_closest = st[ST_RAYS_CLOSEST];

@@ -1625,13 +1625,14 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
 }
 
 // The rest of one_bounce_radiance_importance and global_illumination (src/raytracer.rs:282-326).
-// k_shade_b waits on memory (VALU 0.3 busy): 8 resident waves per SIMD with 4 light-sample records in flight per lane beat 4 waves with 8
-// (a 64-register budget, 52 B of spills): 21.7 -> 19.8 ms per 16-spp frame of config 4.
+// k_shade_b waits on memory (VALU 0.36 busy): 8 resident waves per SIMD (a 64-register budget, 36 B of spills) with 2 light-sample records in
+// flight per lane; measured per 32-spp frame of config 4, one lane: 2 in flight 39.2 ms of shading kernels, 1: 46.5, 3: 40.0, 4: 41.0;
+// 6 waves: 45.0, 5 waves with 8 in flight: 44.2.
 #ifndef RT_SB_WAVES
 #define RT_SB_WAVES 8
 #endif
 #ifndef RT_SB_BATCH
-#define RT_SB_BATCH 4
+#define RT_SB_BATCH 2
 #endif
 __global__ void __launch_bounds__(RT_BLOCK, RT_SB_WAVES) k_shade_b(DevScene sc, PassCtx pc, uint32_t level) {
     const uint32_t n = pc.vcounts[level];
