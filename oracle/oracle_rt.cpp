@@ -295,6 +295,13 @@ struct Ray {
 inline Ray ray_new(V3 o, V3 d) { Ray r = {o, normalized(d)}; return r; }          // geo.rs:19-24
 inline Ray ray_prenorm(V3 o, V3 d) { Ray r = {o, d}; return r; }                   // geo.rs:28-30
 
+// Test switch (orc_set_double_trig): the samplers evaluate sin / cos / acos with the double-precision definitions (orc_sincos, orc_acosf:
+// <= 0.5001 ulp) instead of the single-precision forms the kernels share.  The two must give statistically the same image
+// (tests/test_oracle_math.py), so that a defect of the single-precision forms cannot hide behind goldens regenerated with them.
+static bool g_double_trig = false;
+inline void sampler_sincos(float x, float* s, float* c) { if (g_double_trig) orc_sincos(x, s, c); else orc_sincos_s(x, s, c); }
+inline float sampler_acos(float u) { return g_double_trig ? orc_acosf(u) : orc_acos_s(u); }
+
 // geo.rs:101-114
 inline V3 random_hemisphere(Rng* rng) {
     float xi1 = rng_f32(rng);
@@ -303,7 +310,7 @@ inline V3 random_hemisphere(Rng* rng) {
     float sin_theta = std::sqrt(1.0f - xi1 * xi1);
     float phi = 2.0f * PI_F * xi2;
     float sin_phi, cos_phi;
-    orc_sincos_s(phi, &sin_phi, &cos_phi);
+    sampler_sincos(phi, &sin_phi, &cos_phi);
     return v3(sin_theta * cos_phi, sin_theta * sin_phi, cos_theta);
 }
 // geo.rs:118-132
@@ -325,10 +332,10 @@ inline V3 random_sphere(Rng* rng) {
     float xi1 = rng_f32(rng);
     float xi2 = rng_f32(rng);
     float theta = 2.0f * PI_F * xi1;
-    float phi = orc_acos_s(1.0f - 2.0f * xi2);
+    float phi = sampler_acos(1.0f - 2.0f * xi2);
     float sp_, cp_, st_, ct_;
-    orc_sincos_s(phi, &sp_, &cp_);
-    orc_sincos_s(theta, &st_, &ct_);
+    sampler_sincos(phi, &sp_, &cp_);
+    sampler_sincos(theta, &st_, &ct_);
     return v3(sp_ * ct_, sp_ * st_, cp_);
 }
 
@@ -1323,6 +1330,7 @@ void orc_rng_raw(uint64_t state, uint32_t n, uint32_t* out) {
     Rng r; r.s = state;
     for (uint32_t i = 0; i < n; ++i) out[i] = rng_u32(&r);
 }
+void orc_set_double_trig(int on) { g_double_trig = on != 0; }
 float orc_math_sin(float x) { return orc_sinf(x); }
 float orc_math_cos(float x) { return orc_cosf(x); }
 float orc_math_acos(float x) { return orc_acosf(x); }

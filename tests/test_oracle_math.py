@@ -78,3 +78,27 @@ def test_pow_gamma():
     nz = ref > 0
     assert _max_ulp(got[nz], ref[nz]) <= 0.5001
     assert L.orc_math_pow(C.c_float(0.0), C.c_float(g)) == 0.0 and L.orc_math_pow(C.c_float(1.0), C.c_float(g)) == 1.0
+
+
+def test_single_precision_trig_renders_like_the_double_precision_definition(teapot_obj):
+    """Goldens 04/05/07 were regenerated when the samplers' sin / cos / acos went from double-precision evaluations (<= 0.5001 ulp) to the
+    single-precision forms (< 0.9 ulp), so they cannot vouch for that change.  This does: the oracle renders the same frame with either
+    definition (orc_set_double_trig), and the images must be the same picture: individual shadow rays flip where a sample point moves by an
+    ulp, but the mean absolute difference of the 8-bit frames stays far below one level and the means of the two frames agree."""
+    import ctypes as C
+    from oracle import binding as ob
+    L = ob.lib()
+    L.orc_set_double_trig.argtypes = [C.c_int]
+    L.orc_set_double_trig.restype = None
+    osc = ob.OracleScene.named("teapot", teapot_obj)
+    p = ob.make_params(width=48, height=48, spp=64, light_samples=4, bounces=3, seed=0x5EED)
+    single = osc.render(p)["rgba"].astype(np.float64)
+    L.orc_set_double_trig(1)
+    try:
+        double = osc.render(p)["rgba"].astype(np.float64)
+    finally:
+        L.orc_set_double_trig(0)
+    assert np.array_equal(osc.render(p)["rgba"], single.astype(np.uint8))                # the switch is off again
+    mad = np.abs(single - double)[:, :, :3].mean()
+    assert mad < 0.5, mad
+    assert abs(single[:, :, :3].mean() - double[:, :, :3].mean()) < 0.05
