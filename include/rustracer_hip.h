@@ -177,6 +177,8 @@ int rt_get_counters(const rt_scene* scene, rt_counters* out);
  *   and they skip k_trace_p (0 = off);
  *   "refill_min" (16), "phase_bias" (16), "shadow_waves" (6), "light_waves" (4), "inner_min" (12), "extend_refill" (24),
  *   "extend_inner" (20), "extend_grid" (8 workgroups per CU): scheduling constants;
+ *   "light_token" 0/1 (default 0): the lanes' k_light launches wait for one another (measured slower); "trace_grid" (8): k_trace_p workgroups per CU
+ *   in eighths of its resident capacity;
  *   "graze_guard" 0/1 (default 0): a Scene::intersect ray that tests a triangle lying within about 2^-10 rad of it stops skipping subtrees by
  *   distance for the rest of its search (measured: k_extend +14 %, no ray of the adversarial test changes: DESIGN.md section 4);
  *   "fail_after_passes" N (default 0 = never): test hook, the render reports RT_ERR_HIP once N passes are enqueued (the error exits join the

@@ -103,6 +103,7 @@ struct Workspace {
     DevBuf<unsigned long long> tmask, tmask_t;
     hipStream_t stream = nullptr;   // lanes run on these when there is more than one
     hipEvent_t done = nullptr;
+    hipEvent_t light = nullptr;     // after this lane's last k_light (light_token)
     void release() {
         counts.release(); hit_id.release(); blist.release(); hit_t.release();
         for (int q = 0; q < 2; ++q) { ray_o[q].release(); ray_d[q].release(); }
@@ -155,7 +156,7 @@ struct rt_scene {
 
     bool opt_stats = false, opt_timing = false;
     uint64_t opt_max_paths = 1ull << 25;
-    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 16, opt_phase_bias = 16, opt_shadow_waves = 6, opt_light_waves = 4, opt_hot = 1, opt_extend_persist = 1, opt_extend_refill = 24, opt_extend_inner = 20, opt_extend_grid = 8, opt_lanes = 3, opt_shaft = 8, opt_graze_guard = 0, opt_trace_grid = 8;
+    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 16, opt_phase_bias = 16, opt_shadow_waves = 6, opt_light_waves = 4, opt_hot = 1, opt_extend_persist = 1, opt_extend_refill = 24, opt_extend_inner = 20, opt_extend_grid = 8, opt_lanes = 3, opt_shaft = 8, opt_graze_guard = 0, opt_trace_grid = 8, opt_light_token = 0;
     uint64_t opt_lane_min_pixels = 65536;
     uint64_t opt_fail_after_passes = 0;          // test hook: render_impl reports a failure once this many passes are enqueued (0 = never)
     uint32_t grid_max = 2048;
@@ -745,6 +746,7 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
         for (uint32_t k = 0; k < n_lanes; ++k) {
             if (!s->ws[k].stream) HIP_TRY(hipStreamCreateWithFlags(&s->ws[k].stream, hipStreamNonBlocking));
             if (!s->ws[k].done) HIP_TRY(hipEventCreateWithFlags(&s->ws[k].done, hipEventDisableTiming));
+            if (!s->ws[k].light) HIP_TRY(hipEventCreateWithFlags(&s->ws[k].light, hipEventDisableTiming));
         }
     }
 
@@ -842,6 +844,8 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
         at_pix[k] = lane_begin[k];
         at_s0[k] = 0;
     }
+    const bool token = n_lanes > 1 && s->opt_light_token != 0;
+    hipEvent_t last_light = nullptr;
     auto run_passes = [&]() -> int {
     for (bool any = true; any;) {
         any = false;
@@ -850,11 +854,13 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
             for (uint32_t j = 0; j < n_lanes; ++j) HIP_TRY(hipStreamSynchronize(streams[j]));
             return fail(RT_ERR_INTERRUPTED, "render interrupted");
         }
+        bool active[RT_MAX_LANES] = {false, false, false, false};
+        // a round: one pass per lane, enqueued level by level across the lanes (lane 0's level l, lane 1's level l, ..., then level l + 1), so that the
+        // k_light launches of the lanes can be chained (light_token below)
         for (uint32_t k = 0; k < n_lanes; ++k) {
             if (at_pix[k] >= lane_begin[k + 1]) continue;
             any = true;
             PassCtx& pc = pcs[k];
-            const DevScene& dv = devs[k];
             const hipStream_t st = streams[k];
             const uint64_t pix0 = at_pix[k];
             const uint32_t s0 = at_s0[k];
@@ -865,10 +871,19 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
             pc.pix0 = (uint32_t)pix0; pc.npix = npix; pc.s0 = s0; pc.spc = spc_now; pc.npaths = npix * spc_now;
             HIP_TRY(hipMemsetAsync(pc.counts, 0, 3 * (levels + 1) * sizeof(uint32_t), st));
             size_t ev;
+            active[k] = true;
             begin_timing(s, st, 2, &ev);
             hipLaunchKernelGGL(k_generate, dim3(grid_for(s, pc.npaths)), dim3(RT_BLOCK), 0, st, pc);
             end_timing(s, st, ev);
-            for (uint32_t level = 0; level < levels; ++level) {
+        }
+        for (uint32_t level = 0; level < levels; ++level) {
+          for (uint32_t k = 0; k < n_lanes; ++k) {
+            if (!active[k]) continue;
+            PassCtx& pc = pcs[k];
+            const DevScene& dv = devs[k];
+            const hipStream_t st = streams[k];
+            size_t ev;
+            {
                 if (interrupt && level && n_lanes == 1) {
                     // interrupt_render() (raytracer.rs:496-498) is honoured between bounce levels: the host waits for the level it
                     // has enqueued, so at most one level of one pass runs on after the flag is raised
@@ -889,17 +904,21 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
                 begin_timing(s, st, 2, &ev);
                 hipLaunchKernelGGL(k_shade_a, dim3(g), dim3(RT_BLOCK), 0, st, dv, pc, level);
                 end_timing(s, st, ev);
-                if (level == P.bounces) break;
+                if (level == P.bounces) continue;
                 if (nlL) {
                     const uint32_t gs = grid_for(s, (uint64_t)pc.npaths * nlL);
                     begin_timing(s, st, hemi ? 0 : (persist ? 3 : 1), &ev);
                     if (persist) {
+                        // "light_token" (off: measured slower, 134.1 vs 127.2 ms per 32-spp frame with three lanes, 140.2 vs 131.8 with two): chain the
+                        // k_light launches of the lanes through events, lane after lane and level after level, so that no two of them share the GPU
+                        if (token && last_light) HIP_TRY(hipStreamWaitEvent(st, last_light, 0));
                         if (s->opt_stats) hipLaunchKernelGGL((k_light<true, 4>), dim3(g), dim3(RT_BLOCK), 0, st, dv, pc, level, s->hot_table);
                         else if (s->opt_light_waves >= 8) hipLaunchKernelGGL((k_light<false, 8>), dim3(g), dim3(RT_BLOCK), 0, st, dv, pc, level, s->hot_table);
                         else if (s->opt_light_waves >= 6) hipLaunchKernelGGL((k_light<false, 6>), dim3(g), dim3(RT_BLOCK), 0, st, dv, pc, level, s->hot_table);
                         else if (s->opt_light_waves >= 5) hipLaunchKernelGGL((k_light<false, 5>), dim3(g), dim3(RT_BLOCK), 0, st, dv, pc, level, s->hot_table);
                         else hipLaunchKernelGGL((k_light<false, 4>), dim3(g), dim3(RT_BLOCK), 0, st, dv, pc, level, s->hot_table);
                         end_timing(s, st, ev);
+                        if (token) { HIP_TRY(hipEventRecord(s->ws[k].light, st)); last_light = s->ws[k].light; }
                         begin_timing(s, st, 2, &ev);
                         if (s->opt_stats) hipLaunchKernelGGL(k_binary<true>, dim3(64), dim3(RT_BLOCK), 0, st, dv, pc, level);
                         else hipLaunchKernelGGL(k_binary<false>, dim3(64), dim3(RT_BLOCK), 0, st, dv, pc, level);
@@ -928,6 +947,13 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
                 hipLaunchKernelGGL(k_shade_b, dim3(g), dim3(RT_BLOCK), 0, st, dv, pc, level);
                 end_timing(s, st, ev);
             }
+          }
+        }
+        for (uint32_t k = 0; k < n_lanes; ++k) {
+            if (!active[k]) continue;
+            PassCtx& pc = pcs[k];
+            const hipStream_t st = streams[k];
+            size_t ev;
             begin_timing(s, st, 2, &ev);
             hipLaunchKernelGGL(k_resolve, dim3(grid_for(s, pc.npix)), dim3(RT_BLOCK), 0, st, pc);
             end_timing(s, st, ev);
@@ -1063,6 +1089,7 @@ void rt_scene_destroy(rt_scene* s) {
         s->ws[k].release();
         if (s->ws[k].stream) (void)hipStreamDestroy(s->ws[k].stream);
         if (s->ws[k].done) (void)hipEventDestroy(s->ws[k].done);
+        if (s->ws[k].light) (void)hipEventDestroy(s->ws[k].light);
     }
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     s->w_accum.release(); s->w_jump.release(); s->w_stats.release();
@@ -1314,6 +1341,7 @@ int rt_set_option(rt_scene* s, const char* name, uint64_t value) {
     else if (n == "extend_refill") { s->opt_extend_refill = value > 64 ? 64 : (value < 1 ? 1 : (uint32_t)value); s->dev.extend_refill_min = s->opt_extend_refill; }
     else if (n == "extend_inner") { s->opt_extend_inner = value > 64 ? 64 : (uint32_t)value; s->dev.extend_inner_min = s->opt_extend_inner; }
     else if (n == "extend_grid") s->opt_extend_grid = value < 1 ? 1 : (uint32_t)value;
+    else if (n == "light_token") s->opt_light_token = value ? 1 : 0;
     else if (n == "trace_grid") s->opt_trace_grid = value < 1 ? 1 : (uint32_t)value;
     else if (n == "graze_guard") { s->opt_graze_guard = value ? 1 : 0; s->dev.graze_guard = s->opt_graze_guard; }
     else if (n == "fail_after_passes") s->opt_fail_after_passes = value;
@@ -1331,7 +1359,7 @@ int rt_get_option(const rt_scene* s, const char* name, uint64_t* value) {
         {"persist", s->opt_persist}, {"hot", s->opt_hot}, {"shadow_waves", s->opt_shadow_waves}, {"light_waves", s->opt_light_waves},
         {"refill_min", s->opt_refill_min}, {"phase_bias", s->opt_phase_bias}, {"inner_min", s->opt_inner_min}, {"lanes", s->opt_lanes},
         {"lane_min_pixels", s->opt_lane_min_pixels}, {"extend_persist", s->opt_extend_persist}, {"extend_refill", s->opt_extend_refill},
-        {"extend_inner", s->opt_extend_inner}, {"extend_grid", s->opt_extend_grid}, {"shaft", s->opt_shaft}, {"trace_grid", s->opt_trace_grid}, {"graze_guard", s->opt_graze_guard}};
+        {"extend_inner", s->opt_extend_inner}, {"extend_grid", s->opt_extend_grid}, {"shaft", s->opt_shaft}, {"trace_grid", s->opt_trace_grid}, {"light_token", s->opt_light_token}, {"graze_guard", s->opt_graze_guard}};
     for (const auto& e : table)
         if (n == e.name) { *value = e.v; return RT_OK; }
     return fail(RT_ERR_INVALID, "unknown option '" + n + "'");

@@ -885,6 +885,31 @@ __device__ __forceinline__ uint32_t block_append(bool keep, uint32_t* counter, u
     return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
+// block_append that also groups what it appends by a class 0..2: within the workgroup's run the entries of class 0 come first, then class 1, then
+// class 2 (each in thread order).  k_shade_a uses it to put the vertices whose own-object test takes the same arm of k_light next to each other,
+// so that fewer of k_light's waves run every arm.  s_tmp: 3 * RT_BLOCK / 64 + 1 words.
+__device__ __forceinline__ uint32_t block_append_classed(bool keep, uint32_t cls, uint32_t* counter, uint32_t* s_tmp) {
+    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+    unsigned long long m[3];
+#pragma unroll
+    for (uint32_t c = 0; c < 3u; ++c) {
+        m[c] = __ballot(keep && cls == c);
+        if (lane == 0) s_tmp[c * (RT_BLOCK / 64) + wave] = (uint32_t)__popcll(m[c]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t i = 0; i < 3u * (RT_BLOCK / 64); ++i) total += s_tmp[i];
+        s_tmp[3 * (RT_BLOCK / 64)] = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t base = s_tmp[3 * (RT_BLOCK / 64)];
+    for (uint32_t i = 0; i < cls * (RT_BLOCK / 64) + wave; ++i) base += s_tmp[i];          // the classes before, then the waves before in this class
+    __syncthreads();
+    const unsigned long long mine = cls == 0u ? m[0] : (cls == 1u ? m[1] : m[2]);
+    return base + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull));
+}
+
 // Sum of v over the workgroup, returned to thread 0 only.  s_tmp: RT_BLOCK / 64 words.
 __device__ __forceinline__ uint32_t block_sum_to_thread0(uint32_t v, uint32_t* s_tmp) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
@@ -1115,14 +1140,14 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_a(DevScene sc, PassCtx pc, u
     const uint32_t bounces_left = pc.P.bounces - level;
     const float4* ro = pc.ray_o[level & 1];
     const float4* rd = pc.ray_d[level & 1];
-    __shared__ uint32_t s_tmp[RT_BLOCK / 64 + 1];
+    __shared__ uint32_t s_tmp[3 * (RT_BLOCK / 64) + 1];
     uint32_t n_alive = 0, n_alive_tri = 0;
     // rays that found a surface to light are compacted into the vertex queue (misses and depth-0 hits end here)
     for (uint32_t e0 = blockIdx.x * RT_BLOCK; e0 < n; e0 += gridDim.x * RT_BLOCK) {
         const uint32_t e = e0 + threadIdx.x;
         bool alive = false;
         float4 vp = make_float4(0, 0, 0, 0), vn = vp, vs = vp;
-        uint32_t id = RT_MISS;
+        uint32_t id = RT_MISS, cls = 0u;
         if (e < n) {
             const float4 o4 = ro[e];
             const uint32_t slot = __float_as_uint(o4.w);
@@ -1142,10 +1167,19 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_a(DevScene sc, PassCtx pc, u
                     vn = make_float4(nrm.x, nrm.y, nrm.z, __uint_as_float(id + 1u));
                     vs = make_float4(o4.w, d.x, d.y, d.z);
                     alive = true;
+                    if (id >= sc.n_tri) {
+                        cls = 2u;
+                    } else {
+                        const float4* tp = sc.tris + 3 * (size_t)id;
+                        const float4 A = tp[0], B = tp[1], C = tp[2];
+                        cls = (lo3(A.x, B.x, C.x) == hi3(A.x, B.x, C.x) || lo3(A.y, B.y, C.y) == hi3(A.y, B.y, C.y) || lo3(A.z, B.z, C.z) == hi3(A.z, B.z, C.z)) ? 0u : 1u;
+                    }
                 }
             }
         }
-        const uint32_t q = block_append(alive, &pc.vcounts[level], s_tmp);
+        // the order inside the workgroup's run follows the arm of k_light's own-object test: vertices on triangles with an axis-flat box (walls: they
+        // walk a beam), on other triangles (mesh: no beam), on spheres (the arm with the square root)
+        const uint32_t q = block_append_classed(alive, cls, &pc.vcounts[level], s_tmp);
         if (alive) { pc.vP[q] = vp; pc.vN[q] = vn; pc.vS[q] = vs; }
         n_alive += alive ? 1u : 0u;
         n_alive_tri += (alive && id < sc.n_tri) ? 1u : 0u;

@@ -366,6 +366,7 @@ def test_render_lanes_do_not_change_a_pixel(scenes):
             for lanes, max_paths in ((1, 0), (2, 0), (3, 4096), (4, 1000), (4, 0)):
                 gsc.set_option("lanes", lanes)
                 gsc.set_option("max_paths", max_paths)
+                gsc.set_option("light_token", 1 if lanes == 3 else 0)      # the lanes' k_light launches chained through events
                 got, cnt = gpu_render(gsc, p)
                 assert np.array_equal(got, ref["rgba"]), (est, shard, lanes, max_paths, int((got != ref["rgba"]).sum()))
                 assert cnt["rays_closest"] == ref["intersect_calls"] and cnt["rays_shadow"] == ref["occluded_calls"], (est, shard, lanes, max_paths)
@@ -373,6 +374,7 @@ def test_render_lanes_do_not_change_a_pixel(scenes):
         gsc.set_option("lanes", 3)
         gsc.set_option("max_paths", 0)
         gsc.set_option("lane_min_pixels", 65536)
+        gsc.set_option("light_token", 0)
 
 
 def test_coplanar_neighbours_of_a_tessellated_wall(gpu):
