@@ -294,7 +294,7 @@ def test_occluder_cache_and_scheduling_switches_do_not_change_a_pixel(gpu):
     assert 0 < c_hot["trace_steps"][5] < c_cold["trace_steps"][5]      # rays handed to k_trace_p: fewer with the cache
 
 
-def _floaters_scene(n_tri=260, n_sph=60, seed=5):
+def _floaters_scene(n_tri=260, n_sph=60, seed=5, extra_lamps=0):
     """new_specular's room with a second, small lamp low in it (so that path vertices lie beside, below, above and inside the box of a
     light: every sign class of a beam's direction interval) and many small diffuse triangles and balls floating in the air: beams that
     are clear, beams a floater barely touches, beams it fills."""
@@ -309,8 +309,10 @@ def _floaters_scene(n_tri=260, n_sph=60, seed=5):
     tri = np.concatenate([c + rng.normal(scale=rng.uniform(0.05, 1.2, (n_tri, 1)), size=(n_tri, 3)) for _ in range(3)], axis=1).astype(np.float32)
     nrm = np.tile(np.array([0, 1, 0, 0, 1, 0, 0, 1, 0], np.float32), (n_tri, 1))
     balls = np.concatenate([rng.uniform([-18, -18, -66], [18, 16, -30], (n_sph, 3)), rng.uniform(0.05, 1.5, (n_sph, 1))], axis=1).astype(np.float32)
-    sph = np.concatenate([e["sph"], np.array([[6.0, -12.0, -45.0, 0.6]], np.float32), balls])
-    sph_mat = np.concatenate([e["sph_mat"], np.array([len(mats) - 2], np.uint32), np.full(n_sph, len(mats) - 1, np.uint32)])
+    lamps = np.concatenate([np.array([[6.0, -12.0, -45.0, 0.6]]), np.concatenate([rng.uniform([-15, -15, -60], [15, 15, -35], (extra_lamps, 3)),
+                                                                                   rng.uniform(0.3, 1.2, (extra_lamps, 1))], axis=1)]).astype(np.float32)
+    sph = np.concatenate([e["sph"], lamps, balls])
+    sph_mat = np.concatenate([e["sph_mat"], np.full(1 + extra_lamps, len(mats) - 2, np.uint32), np.full(n_sph, len(mats) - 1, np.uint32)])
     args = (np.concatenate([e["tri_pos"], tri]), np.concatenate([e["tri_nrm"], nrm]), np.concatenate([e["tri_mat"], np.full(n_tri, len(mats) - 1, np.uint32)]),
             sph, sph_mat, mats)
     return ob.OracleScene.raw(*args), ra.Scene.from_arrays(*args)
@@ -323,6 +325,7 @@ def test_beams_settle_rays_without_changing_a_pixel(scenes):
     cases = [(_floaters_scene(), dict(width=112, height=84, spp=3, light_samples=6, bounces=4, seed=17)),
              (_floaters_scene(n_tri=40, n_sph=4, seed=9), dict(width=96, height=96, spp=2, light_samples=16, bounces=3, seed=3, cam=(3.0, -6.0, -8.0))),
              (_two_light_scene(), dict(width=80, height=60, spp=3, light_samples=8, bounces=5, seed=23)),
+             (_floaters_scene(n_tri=30, n_sph=6, seed=13, extra_lamps=5), dict(width=72, height=54, spp=2, light_samples=3, bounces=3, seed=41)),   # 7 lights: more than carry an occluder cache
              (scenes("dragon_small"), dict(width=128, height=96, spp=2, light_samples=8, bounces=4, seed=29)),
              (scenes("specular_teapot"), dict(width=96, height=72, spp=2, light_samples=8, bounces=6, seed=31))]
     for (osc, gsc), kw in cases:
