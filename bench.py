@@ -231,10 +231,12 @@ def main():
                              "lanes_per_prim_step": round(ts["prim_lanes"] / max(ts["prim_steps"], 1), 1),
                              "lanes_per_refill": round(ts["refill_lanes"] / max(ts["refills"], 1), 1)}}
             # k_light, per light sample: the vertex record (position 16 B, normal 16 B, path slot 8 B, RNG state 8 B) is read once per
-            # vertex and serves nlL samples; every sample writes 1/64 of two row masks (2 x 8 B); a ray it cannot settle as blocked writes
-            # its 16-B record (direction, distance), and one that still has to be traced 16 B more (1/d of the box test, flags).
-            settled_frac = sc["shaft"][3] / n_shadow
-            b_light = 48.0 / max(nlL, 1) + 16.0 / 64.0 + 16.0 * (traced_frac + settled_frac) + 16.0 * traced_frac
+            # vertex and serves nlL samples; every sample writes 1/64 of two row masks (2 x 8 B); a ray it can settle neither as blocked nor,
+            # inside a clear beam, as visible and summed writes its 16-B record (direction, distance), and one that still has to be traced 16 B
+            # more (1/d of the box test, flags).
+            # A settled ray whose term k_light adds itself leaves none; each (vertex, light) writes the 16 B of that sum.
+            settled_frac = (sc["shaft"][3] - sc["trace_steps"][7]) / n_shadow
+            b_light = 48.0 / max(nlL, 1) + 16.0 / 64.0 + 16.0 / max(a.light_samples, 1) + 16.0 * (traced_frac + settled_frac) + 16.0 * traced_frac
             kernels["k_light"] = {
                 "what": "Object::sample_l for every (vertex, light sample) + the test of the object the ray starts on + the per-light occluder cache",
                 "unit": "light sample", "bytes_per_unit": round(b_light, 2), "units_per_launch": round(cnt["rays_shadow"] / launches, 1),
@@ -243,7 +245,8 @@ def main():
             if sh[0]:
                 # the per-(vertex, light) beam walk: how many beams were walked, how many were clear, what the walk cost
                 kernels["k_light"]["shaft"] = {"beams_walked_per_vertex_light": round(sh[0] * a.light_samples / n_shadow, 4), "clear_fraction_of_walked": round(sh[1] / sh[0], 4),
-                                               "nodes_per_walk": round(sh[2] / sh[0], 3), "rays_settled_visible_fraction_of_is_occluded_rays": round(sh[3] / n_shadow, 4)}
+                                               "nodes_per_walk": round(sh[2] / sh[0], 3), "rays_settled_visible_fraction_of_is_occluded_rays": round(sh[3] / n_shadow, 4),
+                                               "of_them_summed_in_k_light": round(sc["trace_steps"][7] / max(sh[3], 1), 4)}
         else:
             # binary-tree kernel (option wide=0 / persist=0, or a scene outside the 8-wide tree's range): SURVEY.md §8(d) formula
             b_shadow = (80.0 * sc["shadow_wide"] + 64.0 * sc["shadow_inner"] + 48.0 * sc["shadow_tris"] + 16.0 * sc["shadow_sphs"]) / n_shadow + 48.0

@@ -79,7 +79,8 @@ typedef struct rt_counters {
     uint64_t shadow_wide;     /* 8-wide occlusion-BVH nodes (80 B) fetched by is_occluded rays ("stats" on) */
     double   kernel_ms_light; /* HIP-event time of k_light alone (Object::sample_l, own-object test, occluder cache), timing enabled */
     uint64_t trace_steps[8];  /* persistent traversal kernel, "stats" on: wave-wide node steps, lanes in them, primitive steps, lanes, refills, lanes,
-                               * primitive records whose own box the ray misses (false candidates of the quantised tree), spare */
+                               * primitive records whose own box the ray misses (false candidates of the quantised tree); [7]: light-sample rays of clear beams whose
+                               * term k_light added to the vertex's sum itself (no record written, "light_sum" option) */
     uint64_t shaft[4];        /* per-(vertex, light) beam test of k_light ("shaft" option), "stats" on: beams walked, beams found clear, nodes
                                * visited by the walks, light-sample rays settled as visible without a traversal */
 } rt_counters;
@@ -174,7 +175,8 @@ int rt_get_counters(const rt_scene* scene, rt_counters* out);
  *   k_extend_p, which refills finished lanes (default 1);
  *   "shaft" 0..16 (default 8): k_light walks the occlusion BVH once per (vertex, light) with the convex hull of the vertex and
  *   the light's box, visiting at most that many nodes; a beam that can meet no primitive record settles its unblocked rays as visible
- *   and they skip k_trace_p (0 = off);
+ *   and they skip k_trace_p (0 = off); "light_sum" 0/1 (default 1): k_light adds the terms of those rays to the vertex's sum itself, in sample
+ *   order, and writes no record for them (0: every visible ray leaves a record for k_shade_b);
  *   "refill_min" (16), "phase_bias" (16), "shadow_waves" (6), "light_waves" (4), "inner_min" (12), "extend_refill" (24),
  *   "extend_inner" (20), "extend_grid" (8 workgroups per CU): scheduling constants;
  *   "light_token" 0/1 (default 0): the lanes' k_light launches wait for one another (measured slower); "trace_grid" (8): k_trace_p workgroups per CU
@@ -182,7 +184,9 @@ int rt_get_counters(const rt_scene* scene, rt_counters* out);
  *   "graze_guard" 0/1 (default 0): a Scene::intersect ray that tests a triangle lying within about 2^-10 rad of it stops skipping subtrees by
  *   distance for the rest of its search (measured: k_extend +14 %, no ray of the adversarial test changes: DESIGN.md section 4);
  *   "fail_after_passes" N (default 0 = never): test hook, the render reports RT_ERR_HIP once N passes are enqueued (the error exits join the
- *   render lanes like the normal one). */
+ *   render lanes like the normal one); "force_binary" m (a bit mask; default 0 = never): test hook, the light samples with
+ *   (vertex index + sample index) & m == 0 go to k_binary (the exact binary-tree fallback for rays unfit for the 8-wide tree) whatever their
+ *   ray looks like: 1 = every second one, 7 = every eighth, 0x80000000 = all. */
 int rt_set_option(rt_scene* scene, const char* name, uint64_t value);
 /* The current value of an option of rt_set_option (no reference counterpart). */
 int rt_get_option(const rt_scene* scene, const char* name, uint64_t* value);

@@ -156,7 +156,7 @@ struct rt_scene {
 
     bool opt_stats = false, opt_timing = false;
     uint64_t opt_max_paths = 1ull << 25;
-    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 16, opt_phase_bias = 16, opt_shadow_waves = 6, opt_light_waves = 4, opt_hot = 1, opt_extend_persist = 1, opt_extend_refill = 24, opt_extend_inner = 20, opt_extend_grid = 8, opt_lanes = 3, opt_shaft = 8, opt_graze_guard = 0, opt_trace_grid = 8, opt_light_token = 0;
+    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 16, opt_phase_bias = 16, opt_shadow_waves = 6, opt_light_waves = 4, opt_hot = 1, opt_extend_persist = 1, opt_extend_refill = 24, opt_extend_inner = 20, opt_extend_grid = 8, opt_lanes = 3, opt_shaft = 8, opt_graze_guard = 0, opt_trace_grid = 8, opt_light_token = 0, opt_light_sum = 1, opt_force_binary = 0;
     uint64_t opt_lane_min_pixels = 65536;
     uint64_t opt_fail_after_passes = 0;          // test hook: render_impl reports a failure once this many passes are enqueued (0 = never)
     uint32_t grid_max = 2048;
@@ -787,7 +787,7 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
             if (!rc && persist) rc = w.tmask.ensure(cap_slots / 64);
             if (!rc && persist) rc = w.tmask_t.ensure(cap_slots / 64);
             if (!rc && !persist && !in_wave) rc = w.contrib.ensure(cap_paths * (nlL ? nlL : 1));
-            if (!rc) rc = w.direct.ensure(cap_paths);
+            if (!rc) rc = w.direct.ensure(persist ? cap_paths * (n_groups ? n_groups : 1) : cap_paths);
             if (!rc) rc = w.stackA.ensure(per_level);
             if (!rc) rc = w.stackB.ensure(per_level);
             if (!rc) rc = w.radiance.ensure(cap_paths);
@@ -812,7 +812,7 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
         pc.P = P;
         pc.seed_mixed = mix64(P.seed);
         pc.tiles_x = sh.tiles_x; pc.n_tiles = sh.n_tiles;
-        pc.n_groups = n_groups; pc.nlL = nlL;
+        pc.n_groups = n_groups; pc.nlL = nlL; pc.vstride = (uint32_t)((uint64_t)npix_chunk * spc); pc.light_sum = s->opt_light_sum; pc.force_binary = s->opt_force_binary;
         pc.counts = w.counts.p; pc.vcounts = w.counts.p + (levels + 1); pc.bcounts = w.counts.p + 2 * (levels + 1); pc.vS = w.vS.p;
         for (int q = 0; q < 2; ++q) { pc.ray_o[q] = w.ray_o[q].p; pc.ray_d[q] = w.ray_d[q].p; }
         pc.hit_id = w.hit_id.p; pc.hit_t = w.hit_t.p;
@@ -1345,6 +1345,8 @@ int rt_set_option(rt_scene* s, const char* name, uint64_t value) {
     else if (n == "trace_grid") s->opt_trace_grid = value < 1 ? 1 : (uint32_t)value;
     else if (n == "graze_guard") { s->opt_graze_guard = value ? 1 : 0; s->dev.graze_guard = s->opt_graze_guard; }
     else if (n == "fail_after_passes") s->opt_fail_after_passes = value;
+    else if (n == "light_sum") s->opt_light_sum = value ? 1 : 0;
+    else if (n == "force_binary") s->opt_force_binary = (uint32_t)value;
     else if (n == "shaft") s->opt_shaft = value > RT_STACK_LDS ? RT_STACK_LDS : (uint32_t)value;
     else if (n == "inner_min") { s->opt_inner_min = value > 64 ? 64 : (uint32_t)value; s->dev.inner_min = s->opt_inner_min; }
     else return fail(RT_ERR_INVALID, "unknown option '" + n + "'");
@@ -1359,7 +1361,7 @@ int rt_get_option(const rt_scene* s, const char* name, uint64_t* value) {
         {"persist", s->opt_persist}, {"hot", s->opt_hot}, {"shadow_waves", s->opt_shadow_waves}, {"light_waves", s->opt_light_waves},
         {"refill_min", s->opt_refill_min}, {"phase_bias", s->opt_phase_bias}, {"inner_min", s->opt_inner_min}, {"lanes", s->opt_lanes},
         {"lane_min_pixels", s->opt_lane_min_pixels}, {"extend_persist", s->opt_extend_persist}, {"extend_refill", s->opt_extend_refill},
-        {"extend_inner", s->opt_extend_inner}, {"extend_grid", s->opt_extend_grid}, {"shaft", s->opt_shaft}, {"trace_grid", s->opt_trace_grid}, {"light_token", s->opt_light_token}, {"graze_guard", s->opt_graze_guard}};
+        {"extend_inner", s->opt_extend_inner}, {"extend_grid", s->opt_extend_grid}, {"shaft", s->opt_shaft}, {"trace_grid", s->opt_trace_grid}, {"light_token", s->opt_light_token}, {"graze_guard", s->opt_graze_guard}, {"light_sum", s->opt_light_sum}, {"force_binary", s->opt_force_binary}};
     for (const auto& e : table)
         if (n == e.name) { *value = e.v; return RT_OK; }
     return fail(RT_ERR_INVALID, "unknown option '" + n + "'");

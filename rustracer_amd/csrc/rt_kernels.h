@@ -107,7 +107,10 @@ struct PassCtx {
     float4* vN;                      // (shading normal, bits: hit object id + 1)
     uint64_t* rng;                   // per path slot
     float4* contrib;                 // per (vertex, light sample): (rgb, visible); only when !in_wave
-    float4* direct;                  // per vertex: light-sample sum (in_wave)
+    float4* direct;                  // per vertex: light-sample sum (in_wave); persist: [light group][vertex, stride vstride] (what k_light summed itself, records left ? 1 : 0)
+    uint32_t vstride;                // vertices the workspace holds (stride of `direct` per light group)
+    uint32_t light_sum;              // k_light adds the terms of the samples it settles as visible itself (option "light_sum")
+    uint32_t force_binary;           // test hook (option "force_binary", a bit mask m != 0): the light samples with (vertex + sample) & m == 0 are handed to k_binary as if their rays were unfit for the 8-wide tree
     uint32_t in_wave;                // nlL divides 64: k_shadow sums a vertex's light samples inside the wave
     unsigned long long* tmask;       // per row (64 vertices x one light sample), k_light: the vertices whose ray is not yet settled as blocked
     unsigned long long* tmask_t;     // per row: those of them k_trace_p still has to trace (tmask minus the rays a clear shaft settles as visible)
@@ -128,7 +131,7 @@ struct PassCtx {
 
 // traversal work is counted per ray class: [ST_C_*] closest-hit rays, [ST_S_*] shadow (any-hit) rays
 enum { ST_RAYS_CLOSEST = 0, ST_RAYS_SHADOW, ST_C_INNER, ST_C_TRIS, ST_C_SPHS, ST_S_INNER, ST_S_TRIS, ST_S_SPHS, ST_HITS_TRI, ST_HITS_SPH, ST_S_WIDE,
-       ST_P_NODE_STEPS, ST_P_NODE_LANES, ST_P_PRIM_STEPS, ST_P_PRIM_LANES, ST_P_REFILLS, ST_P_REFILL_LANES, ST_P_BOX_MISS, ST_P_SPARE,
+       ST_P_NODE_STEPS, ST_P_NODE_LANES, ST_P_PRIM_STEPS, ST_P_PRIM_LANES, ST_P_REFILLS, ST_P_REFILL_LANES, ST_P_BOX_MISS, ST_L_SUMMED,
        ST_SHAFT_TRIED, ST_SHAFT_CLEAR, ST_SHAFT_STEPS, ST_SHAFT_RAYS, ST_COUNT };
 
 // ---------------------------------------------------------------------------------------------
@@ -1306,6 +1309,26 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SHADOW_WAVES) k_shadow(DevScene s
 #define RT_LR_LANE_SHIFT 23         // bits 23..28: the ray's vertex within its tile of 64 (bits 0..22: the record of the object it starts on)
 #define RT_LR_SKIP_SIB 0x20000000u  // the coplanar neighbour of the triangle the ray starts on (sc.wsib) cannot be a candidate: k_trace_p skips its record too
 #define RT_LR_BINARY 0x40000000u    // the ray has a non-finite or huge 1/d: k_binary settles it on the binary tree, k_trace_p drops it
+// One visible light sample's term of one_bounce_radiance_importance's sum (raytracer.rs:276-279), shared by k_light (the samples it settles as
+// visible and sums itself) and k_shade_b (the ones that went through k_trace_p / k_binary): what depends on (vertex, light) only, then the term.
+struct LightPdf { float num0, den, rcp_den; bool den_mid; };
+__device__ __forceinline__ LightPdf light_pdf_setup(vec3 p, float4 cr) {
+    // Object::sample_l's cos_a = (d_c^2 + r^2 - d_s^2) / (2 d_c r), objects.rs:109-113: the divisor and its reciprocal are the vertex's
+    LightPdf lp;
+    const float d_c = length3(sub(xyz(cr), p));
+    lp.num0 = d_c * d_c + cr.w * cr.w;
+    lp.den = 2.0f * d_c * cr.w;
+    lp.den_mid = div_range(lp.den);
+    lp.rcp_den = rcp_mid(lp.den);
+    return lp;
+}
+__device__ __forceinline__ vec3 light_term(const LightPdf& lp, vec3 base, vec3 nrm, vec3 wi, float d_s) {
+    const float num = lp.num0 - d_s * d_s;
+    const float cos_a = (lp.den_mid && div_range(num)) ? div_mid(num, lp.den, lp.rcp_den) : num / lp.den;
+    const float pdf = 2.0f * RT_PI * (1.0f - cos_a);
+    const float cos_theta = fabsf(dot3(wi, nrm));                                  // raytracer.rs:278
+    return scale(scale(base, cos_theta), pdf);                                     // raytracer.rs:279
+}
 __device__ __forceinline__ size_t ls_slot(uint32_t e, uint32_t j, uint32_t nlL) {
     return (size_t)(e >> 6) * (64u * (size_t)nlL) + (size_t)j * 64u + (e & 63u);
 }
@@ -1313,7 +1336,7 @@ template <bool STATS, int WAVES>   // WAVES: waves per SIMD the register budget 
 __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx pc, uint32_t level, HotTable hot) {
     TravStats tst = {0, 0, 0, 0, 0};
     __shared__ uint32_t s_shaft[RT_STACK_LDS * RT_BLOCK];                      // shaft_clear()'s stack, [entry][lane]
-    uint32_t sh_tried = 0u, sh_clear = 0u, sh_steps = 0u, sh_rays = 0u;        // STATS
+    uint32_t sh_tried = 0u, sh_clear = 0u, sh_steps = 0u, sh_rays = 0u, sh_summed = 0u;        // STATS
     const uint32_t shaft_steps = pc.shaft_steps < RT_STACK_LDS ? pc.shaft_steps : RT_STACK_LDS;
     const uint32_t n = pc.vcounts[level], n_round = (n + 63u) & ~63u;
     const uint32_t nlL = pc.nlL, L = pc.P.light_samples;
@@ -1369,6 +1392,10 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
         const float own_tn = dot3(own_s2, own_e2);
         const bool p_wide_ok = fabsf(p.x) <= WIDE_COORD_MAX && fabsf(p.y) <= WIDE_COORD_MAX && fabsf(p.z) <= WIDE_COORD_MAX;
         uint64_t rng = rng0;                                                   // the vertex's stream: two draws per light sample, in sample order
+        // Object::bsdf of the vertex's material (objects.rs:118-128): the factor of every light sample k_light sums itself (below)
+        const float4 m0 = sc.mats[2 * __float_as_uint(P4.w)];
+        const vec3 bsdf = __float_as_uint(m0.x) == RT_BSDF_DIFFUSE ? scale(mk(m0.y, m0.z, m0.w), 1.0f / RT_PI) : mk(0.0f, 0.0f, 0.0f);
+        const vec3 nrm = xyz(N4);
         size_t row = ls_slot(e0 & ~63u, 0, nlL);                               // first slot of the row of (this tile, sample j): + 64 per sample
         unsigned long long* row_mask = pc.tmask + (size_t)(e0 >> 6) * nlL;    // mask of that row: + 1 per sample
         unsigned long long* row_mask_t = pc.tmask_t + (size_t)(e0 >> 6) * nlL;
@@ -1410,6 +1437,14 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
                   if (STATS && live) { sh_tried++; sh_steps += steps; sh_clear += clear ? 1u : 0u; }
               }
           }
+          // A ray of a clear beam that is not blocked here is visible, and everything its term of the sum of raytracer.rs:279 needs is in
+          // registers: the vertex adds it right here, in sample order, and the ray leaves no record.  The sum is a chain of f32 additions, so
+          // that holds for the samples BEFORE the first one of this (vertex, light) that does leave a record (a k_binary ray); from there on
+          // the visible ones go to the row as before and k_shade_b carries on from the sum written below.  Same operations, same order as k_shade_b.
+          const vec3 base = mul3(xyz(sc.mats[2 * (sc.sph_aux[light - sc.n_tri].y & ~RT_INFO_BLOCKER) + 1]), bsdf);
+          const LightPdf lp = light_pdf_setup(p, cr);
+          vec3 color = mk(0.0f, 0.0f, 0.0f);
+          bool sum_open = clear && pc.light_sum != 0u, has_rec = false;
           for (uint32_t ls = 0; ls < L; ++ls, ++j, row += 64) {                // for _ in 0..light_samples (raytracer.rs:269)
             const vec3 sp = add(xyz(cr), scale(random_sphere(&rng), cr.w));      // Sphere::random_point, objects.rs:223-226
             const vec3 ps = sub(sp, p);
@@ -1439,6 +1474,7 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
                 br = make_box_ray(p, wi);
                 binary = !wide_ray_ok(br, p);
             }
+            if (pc.force_binary != 0u && ((e0 + j) & pc.force_binary) == 0u) binary = true;
             bool blocked = false;
             if (!binary && (self_is_tri || self_is_sph) && slab_rel(br, own_dnx, own_dny, own_dnz, own_dxx, own_dxy, own_dxz)) {
                 float t = 0.0f;
@@ -1472,13 +1508,18 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
             }
             // a ray not settled here leaves a record: k_trace_p searches the occlusion BVH for a blocker; the few with a 0 * inf = NaN
             // case in their slab test, or far-away coordinates, go to k_binary and the binary tree, which has the crate's NaN behaviour
-            const bool keep = live && !blocked;
+            const bool unblocked = live && !blocked;
+            // rays of a clear beam are settled: k_trace_p never sees them (k_binary's rays are k_binary's either way)
+            const bool to_trace = unblocked && !(clear && !binary);
+            const bool summed = unblocked && !to_trace && sum_open;
+            sum_open = sum_open && !to_trace;
+            const bool keep = unblocked && !summed;             // leaves a record
             const unsigned long long m = __ballot(keep);      // the whole wave is here: one row of 64 slots
-            // rays of a clear beam are settled: k_shade_b finds their record, k_trace_p never sees them (k_binary's rays are k_binary's either way)
-            const bool to_trace = keep && !(clear && !binary);
             const unsigned long long mt = __ballot(to_trace);
-            if (STATS) sh_rays += (keep && !to_trace) ? 1u : 0u;
+            if (STATS) { sh_rays += (unblocked && !to_trace) ? 1u : 0u; sh_summed += summed ? 1u : 0u; }
+            if (summed) color = add(color, light_term(lp, base, nrm, wi, d_s));
             if (keep) {
+                has_rec = true;
                 // place in the row: the rays still to trace first, in lane order, then the settled ones (k_trace_p reads a dense run of records)
                 const unsigned long long mine = to_trace ? mt : (m & ~mt);
                 const size_t at = row + (to_trace ? 0u : (uint32_t)__popcll(mt)) + __builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
@@ -1493,14 +1534,16 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
             }
             if (__lane_id() == 0u) { row_mask[j] = m; row_mask_t[j] = mt; }
           }
+          if (live) pc.direct[(size_t)g * pc.vstride + e] = make_float4(color.x, color.y, color.z, has_rec ? 1.0f : 0.0f);
         }
     }
     flush_stats<STATS>(pc.stats, tst, ST_S_INNER);
     if (STATS) {
         for (int off = 32; off > 0; off >>= 1) {
             sh_tried += __shfl_xor(sh_tried, off); sh_clear += __shfl_xor(sh_clear, off);
-            sh_steps += __shfl_xor(sh_steps, off); sh_rays += __shfl_xor(sh_rays, off);
+            sh_steps += __shfl_xor(sh_steps, off); sh_rays += __shfl_xor(sh_rays, off); sh_summed += __shfl_xor(sh_summed, off);
         }
+        if (__lane_id() == 0u && sh_summed) atomicAdd(&pc.stats[ST_L_SUMMED], (unsigned long long)sh_summed);
         if (__lane_id() == 0u && sh_tried) {
             atomicAdd(&pc.stats[ST_SHAFT_TRIED], (unsigned long long)sh_tried); atomicAdd(&pc.stats[ST_SHAFT_CLEAR], (unsigned long long)sh_clear);
             atomicAdd(&pc.stats[ST_SHAFT_STEPS], (unsigned long long)sh_steps); atomicAdd(&pc.stats[ST_SHAFT_RAYS], (unsigned long long)sh_rays);
@@ -1681,10 +1724,14 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SB_WAVES) k_shade_b(DevScene sc, 
         const uint32_t e = e0 + threadIdx.x;
         bool cont = false;
         float4 o_next = make_float4(0, 0, 0, 0), d_next = make_float4(0, 0, 0, 0);
-        if (e < n) {
-            const float4 N4 = pc.vN[e];
+        // whole tiles of 64: the idle lanes of a level's last tile run along on its last vertex (the row masks below are handed from lane to
+        // lane, which takes every lane awake) and store nothing
+        if ((e & ~63u) < n) {
+            const bool live = e < n;
+            const uint32_t ev = live ? e : n - 1u;
+            const float4 N4 = pc.vN[ev];
             {
-                const float4 P4 = pc.vP[e];
+                const float4 P4 = pc.vP[ev];
                 const uint32_t mat = __float_as_uint(P4.w);
                 const float4 m0 = sc.mats[2 * mat];
                 const vec3 p = xyz(P4), nrm = xyz(N4);
@@ -1699,51 +1746,55 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SB_WAVES) k_shade_b(DevScene sc, 
                         const float4 cr = sc.sph[light - sc.n_tri];
                         const vec3 le = xyz(sc.mats[2 * (sc.sph_aux[light - sc.n_tri].y & ~RT_INFO_BLOCKER) + 1]);
                         const vec3 base = mul3(le, f);
-                        const float d_c = length3(sub(xyz(cr), p));
-                        // Object::sample_l's cos_a = (d_c^2 + r^2 - d_s^2) / (2 d_c r), objects.rs:109-113: the divisor and its reciprocal are the vertex's
-                        const float num0 = d_c * d_c + cr.w * cr.w, den = 2.0f * d_c * cr.w;
-                        const bool den_mid = div_range(den);
-                        const float rcp_den = rcp_mid(den);
-                        vec3 color = mk(0.0f, 0.0f, 0.0f);
+                        const LightPdf lp = light_pdf_setup(p, cr);
+                        // the samples k_light summed itself (the leading ones of a clear beam); the rows hold the rest, if any
+                        const float4 pre = pc.direct[(size_t)g * pc.vstride + ev];
+                        vec3 color = xyz(pre);
+                        if (__ballot(live && pre.w != 0.0f) == 0ull) { l = add(l, scale(color, inv_light_samples)); continue; }     // no record in this wave's rows
                         const size_t row0 = ls_slot(e & ~63u, g * L, pc.nlL);                                  // first slot of the row of sample s: + 64 s
                         const unsigned long long* mrow = pc.tmask + (size_t)(e >> 6) * pc.nlL + (size_t)g * L;  // mask of that row: + s
                         const unsigned long long* mrow_t = pc.tmask_t + (size_t)(e >> 6) * pc.nlL + (size_t)g * L;   // ... and which of them were traced
-                        for (uint32_t s0 = 0; s0 < L; s0 += RT_SB_BATCH) {                         // RT_SB_BATCH samples in flight, then added in sample order
-                            unsigned long long mk8[RT_SB_BATCH], mt8[RT_SB_BATCH];
-                            uint32_t w[RT_SB_BATCH];
-                            float4 r[RT_SB_BATCH];
+                        // The row masks of 32 samples at a time, one per lane (lanes 0..31: tmask, 32..63: tmask_t) in ONE load, then handed round by
+                        // v_readlane: the sample loop's only trips to memory are the records themselves.
+                        for (uint32_t sb = 0; sb < L; sb += 32u) {
+                            const uint32_t cnt = L - sb < 32u ? L - sb : 32u;
+                            unsigned long long mword = 0ull;
+                            if ((lane & 31u) < cnt) mword = (lane < 32u ? mrow : mrow_t)[sb + (lane & 31u)];
+                            const uint32_t mw_lo = (uint32_t)mword, mw_hi = (uint32_t)(mword >> 32);
+                            for (uint32_t s0 = 0; s0 < cnt; s0 += RT_SB_BATCH) {                   // RT_SB_BATCH samples in flight, then added in sample order
+                                unsigned long long mk8[RT_SB_BATCH], mt8[RT_SB_BATCH];
+                                uint32_t w[RT_SB_BATCH];
+                                float4 r[RT_SB_BATCH];
 #pragma unroll
-                            for (uint32_t k = 0; k < RT_SB_BATCH; ++k) { mk8[k] = s0 + k < L ? mrow[s0 + k] : 0ull; mt8[k] = s0 + k < L ? mrow_t[s0 + k] : 0ull; }
-#pragma unroll
-                            for (uint32_t k = 0; k < RT_SB_BATCH; ++k) {
-                                w[k] = RT_LR_BLOCKED;
-                                r[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                                if ((mk8[k] >> lane) & 1ull) {
-                                    // the row holds the traced rays first, then the ones a clear beam settled, each group in lane order (k_light)
-                                    const unsigned long long below = (1ull << lane) - 1ull;
-                                    const uint32_t place = ((mt8[k] >> lane) & 1ull) ? (uint32_t)__popcll(mt8[k] & below) : (uint32_t)(__popcll(mt8[k]) + __popcll(mk8[k] & ~mt8[k] & below));
-                                    const size_t at = row0 + 64 * (size_t)(s0 + k) + place;
-                                    r[k] = pc.lray[at];
-                                    w[k] = __float_as_uint(r[k].w);
+                                for (uint32_t k = 0; k < RT_SB_BATCH; ++k) {
+                                    const uint32_t si = s0 + k;       // (< 32 + RT_SB_BATCH; the lanes read beyond cnt hold 0 or are masked by the test)
+                                    mk8[k] = si < cnt ? ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mw_hi, (int)(si & 31u)) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)mw_lo, (int)(si & 31u)) : 0ull;
+                                    mt8[k] = si < cnt ? ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mw_hi, (int)(32u + (si & 31u))) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)mw_lo, (int)(32u + (si & 31u))) : 0ull;
                                 }
+#pragma unroll
+                                for (uint32_t k = 0; k < RT_SB_BATCH; ++k) {
+                                    w[k] = RT_LR_BLOCKED;
+                                    r[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                                    if ((mk8[k] >> lane) & 1ull) {
+                                        // the row holds the traced rays first, then the ones a clear beam settled, each group in lane order (k_light)
+                                        const unsigned long long below = (1ull << lane) - 1ull;
+                                        const uint32_t place = ((mt8[k] >> lane) & 1ull) ? (uint32_t)__popcll(mt8[k] & below) : (uint32_t)(__popcll(mt8[k]) + __popcll(mk8[k] & ~mt8[k] & below));
+                                        const size_t at = row0 + 64 * (size_t)(sb + s0 + k) + place;
+                                        r[k] = pc.lray[at];
+                                        w[k] = __float_as_uint(r[k].w);
+                                    }
+                                }
+#pragma unroll
+                                for (uint32_t k = 0; k < RT_SB_BATCH; ++k)
+                                    if (!(w[k] & RT_LR_BLOCKED)) color = add(color, light_term(lp, base, nrm, xyz(r[k]), r[k].w));
                             }
-#pragma unroll
-                            for (uint32_t k = 0; k < RT_SB_BATCH; ++k)
-                                if (!(w[k] & RT_LR_BLOCKED)) {
-                                    const float d_s = r[k].w;
-                                    const float num = num0 - d_s * d_s;
-                                    const float cos_a = (den_mid && div_range(num)) ? div_mid(num, den, rcp_den) : num / den;
-                                    const float pdf = 2.0f * RT_PI * (1.0f - cos_a);
-                                    const float cos_theta = fabsf(dot3(xyz(r[k]), nrm));                                  // raytracer.rs:278
-                                    color = add(color, scale(scale(base, cos_theta), pdf));                               // raytracer.rs:279
-                                }
                         }
                         l = add(l, scale(color, inv_light_samples));                // raytracer.rs:282
                     }
                 } else if (pc.in_wave) {
-                    l = xyz(pc.direct[e]);                                          // summed by k_shadow
+                    l = xyz(pc.direct[ev]);                                          // summed by k_shadow
                 } else {
-                    const float4* cp = pc.contrib + (size_t)e * pc.nlL;
+                    const float4* cp = pc.contrib + (size_t)ev * pc.nlL;
                     for (uint32_t g = 0; g < pc.n_groups; ++g) {
                         vec3 color = mk(0.0f, 0.0f, 0.0f);
                         for (uint32_t s = 0; s < L; ++s) {
@@ -1755,6 +1806,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SB_WAVES) k_shade_b(DevScene sc, 
                 }
                 // (what only the rest needs is fetched here, after the sample loop: k_shade_b waits on memory, and registers held across
                 // the loop cost it resident waves)
+                if (live) {
                 const float4 S4 = pc.vS[e], m1 = sc.mats[2 * mat + 1];
                 const uint32_t slot = __float_as_uint(S4.x);
                 l = add(l, xyz(m1));                                                // raytracer.rs:284
@@ -1788,6 +1840,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SB_WAVES) k_shade_b(DevScene sc, 
                         d_next = make_float4(dn.x, dn.y, dn.z, 0.0f);
                         cont = true;
                     }
+                }
                 }
             }
         }

@@ -349,9 +349,26 @@ def test_beams_settle_rays_without_changing_a_pixel(scenes):
                     if budget >= 8:
                         assert clear > 0, (kw, budget, cnt["shaft"])
             assert traced[16] <= traced[8] <= traced[2] <= traced[0] and traced[16] < traced[0], traced       # a larger budget proves more beams clear
+            # The settled rays' terms of the sum (raytracer.rs:279) are added by k_light itself, in sample order, up to the first sample of the
+            # (vertex, light) that leaves a record; "light_sum" 0 leaves every visible ray a record for k_shade_b instead.  "force_binary" hands
+            # every second / eighth / every sample to k_binary, so that records turn up in the middle of clear beams: the sum must close there and k_shade_b carry on.
+            gsc.set_option("shaft", 8)
+            summed = {}
+            for light_sum, force_binary in ((1, 0), (0, 0), (1, 1), (1, 7), (0, 3), (1, 0x80000000)):
+                gsc.set_option("light_sum", light_sum)
+                gsc.set_option("force_binary", force_binary)
+                got, cnt = gpu_render(gsc, p)
+                assert np.array_equal(got, ref["rgba"]), (kw, light_sum, force_binary, int((got != ref["rgba"]).sum()))
+                assert cnt["rays_closest"] == ref["intersect_calls"] and cnt["rays_shadow"] == ref["occluded_calls"], (kw, light_sum, force_binary)
+                summed[(light_sum, force_binary)] = cnt["trace_steps"][7]
+                assert cnt["trace_steps"][7] <= cnt["shaft"][3]
+            assert summed[(1, 0)] > 0 and summed[(0, 0)] == 0 and summed[(0, 3)] == 0 and summed[(1, 0x80000000)] == 0, summed
+            assert 0 < summed[(1, 1)] < summed[(1, 7)] < summed[(1, 0)], summed      # the earlier the first forced record, the shorter the summed prefix
         finally:
             gsc.set_option("stats", 0)
             gsc.set_option("shaft", 8)
+            gsc.set_option("light_sum", 1)
+            gsc.set_option("force_binary", 0)
 
 
 def test_render_lanes_do_not_change_a_pixel(scenes):
