@@ -99,7 +99,7 @@ struct Workspace {
     DevBuf<uint32_t> counts, hit_id, blist;
     DevBuf<float> hit_t;
     DevBuf<float4> ray_o[2], ray_d[2], vP, vN, vS, contrib, direct, stackA, stackB, radiance, lray, linv;
-    DevBuf<uint64_t> rng;
+    DevBuf<uint64_t> rng[3];     // the paths' RNG states: per queued ray (two queues) and per vertex
     DevBuf<unsigned long long> tmask, tmask_t;
     hipStream_t stream = nullptr;   // lanes run on these when there is more than one
     hipEvent_t done = nullptr;
@@ -108,7 +108,7 @@ struct Workspace {
         counts.release(); hit_id.release(); blist.release(); hit_t.release();
         for (int q = 0; q < 2; ++q) { ray_o[q].release(); ray_d[q].release(); }
         vP.release(); vN.release(); vS.release(); contrib.release(); direct.release(); stackA.release(); stackB.release(); radiance.release();
-        lray.release(); linv.release(); rng.release(); tmask.release(); tmask_t.release();
+        lray.release(); linv.release(); for (auto& r : rng) r.release(); tmask.release(); tmask_t.release();
     }
 };
 
@@ -780,7 +780,7 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
             if (!rc) rc = w.vP.ensure(cap_paths);
             if (!rc) rc = w.vN.ensure(cap_paths);
             if (!rc) rc = w.vS.ensure(cap_paths);
-            if (!rc) rc = w.rng.ensure(cap_paths);
+            for (int q = 0; q < 3 && !rc; ++q) rc = w.rng[q].ensure(cap_paths);
             if (!rc && persist) rc = w.lray.ensure(cap_slots);
             if (!rc && persist) rc = w.linv.ensure(cap_slots);
             if (!rc && persist) rc = w.blist.ensure(cap_slots);
@@ -816,7 +816,7 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
         pc.counts = w.counts.p; pc.vcounts = w.counts.p + (levels + 1); pc.bcounts = w.counts.p + 2 * (levels + 1); pc.vS = w.vS.p;
         for (int q = 0; q < 2; ++q) { pc.ray_o[q] = w.ray_o[q].p; pc.ray_d[q] = w.ray_d[q].p; }
         pc.hit_id = w.hit_id.p; pc.hit_t = w.hit_t.p;
-        pc.vP = w.vP.p; pc.vN = w.vN.p; pc.rng = w.rng.p; pc.contrib = w.contrib.p; pc.direct = w.direct.p; pc.in_wave = in_wave ? 1u : 0u;
+        pc.vP = w.vP.p; pc.vN = w.vN.p; pc.qrng[0] = w.rng[0].p; pc.qrng[1] = w.rng[1].p; pc.vR = w.rng[2].p; pc.contrib = w.contrib.p; pc.direct = w.direct.p; pc.in_wave = in_wave ? 1u : 0u;
         pc.lray = w.lray.p; pc.linv = w.linv.p; pc.blist = w.blist.p; pc.tmask = w.tmask.p; pc.tmask_t = w.tmask_t.p; pc.shaft_steps = s->opt_shaft; pc.persist = persist ? 1u : 0u;
         pc.stackA = w.stackA.p; pc.stackB = w.stackB.p; pc.radiance = w.radiance.p; pc.accum = s->w_accum.p;
         pc.jump = s->w_jump.p; pc.stats = s->w_stats.p; pc.rgba = rgba_dev;

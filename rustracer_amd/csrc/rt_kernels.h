@@ -105,7 +105,8 @@ struct PassCtx {
     float* hit_t;
     float4* vP;                      // per vertex, compacted by k_shade_a: (hit point, material index bits)
     float4* vN;                      // (shading normal, bits: hit object id + 1)
-    uint64_t* rng;                   // per path slot
+    uint64_t* qrng[2];               // per queued ray: the path's RNG state (it travels with the ray and the vertex, so that no kernel gathers it by path slot)
+    uint64_t* vR;                    // per vertex: the same, copied by k_shade_a; k_light draws the light samples from it, k_shade_b jumps over them
     float4* contrib;                 // per (vertex, light sample): (rgb, visible); only when !in_wave
     float4* direct;                  // per vertex: light-sample sum (in_wave); persist: [light group][vertex, stride vstride] (what k_light summed itself, records left ? 1 : 0)
     uint32_t vstride;                // vertices the workspace holds (stride of `direct` per light group)
@@ -999,7 +1000,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_generate(PassCtx pc) {
         const bool valid = q < pc.npaths && own_pixel_xy(P, pc.tiles_x, pc.pix0 + pl, &x, &y);
         const uint32_t e = block_append(valid, &pc.counts[0], s_tmp);
         if (!valid) continue;
-        pc.rng[q] = stream_seed(pc.seed_mixed, y * P.width + x, s);
+        pc.qrng[0][e] = stream_seed(pc.seed_mixed, y * P.width + x, s);
         const vec3 d = screen_to_world(P, x, y);
         pc.ray_o[0][e] = make_float4(cam.x, cam.y, cam.z, __uint_as_float(q));
         pc.ray_d[0][e] = make_float4(d.x, d.y, d.z, 0.0f);
@@ -1150,6 +1151,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_a(DevScene sc, PassCtx pc, u
         const uint32_t e = e0 + threadIdx.x;
         bool alive = false;
         float4 vp = make_float4(0, 0, 0, 0), vn = vp, vs = vp;
+        uint64_t vr = 0ull;
         uint32_t id = RT_MISS, cls = 0u;
         if (e < n) {
             const float4 o4 = ro[e];
@@ -1169,6 +1171,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_a(DevScene sc, PassCtx pc, u
                     vp = make_float4(p.x, p.y, p.z, __uint_as_float(mat));
                     vn = make_float4(nrm.x, nrm.y, nrm.z, __uint_as_float(id + 1u));
                     vs = make_float4(o4.w, d.x, d.y, d.z);
+                    vr = pc.qrng[level & 1][e];
                     alive = true;
                     if (id >= sc.n_tri) {
                         cls = 2u;
@@ -1183,7 +1186,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_a(DevScene sc, PassCtx pc, u
         // the order inside the workgroup's run follows the arm of k_light's own-object test: vertices on triangles with an axis-flat box (walls: they
         // walk a beam), on other triangles (mesh: no beam), on spheres (the arm with the square root)
         const uint32_t q = block_append_classed(alive, cls, &pc.vcounts[level], s_tmp);
-        if (alive) { pc.vP[q] = vp; pc.vN[q] = vn; pc.vS[q] = vs; }
+        if (alive) { pc.vP[q] = vp; pc.vN[q] = vn; pc.vS[q] = vs; pc.vR[q] = vr; }
         n_alive += alive ? 1u : 0u;
         n_alive_tri += (alive && id < sc.n_tri) ? 1u : 0u;
     }
@@ -1222,9 +1225,8 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SHADOW_WAVES) k_shadow(DevScene s
         vec3 wi = mk(0.0f, 0.0f, 1.0f), c = mk(0.0f, 0.0f, 0.0f), reflected = mk(0.0f, 0.0f, 0.0f);
         float d_s = 0.0f, cos_theta = 0.0f;
         if (alive) {
-            const uint32_t slot = __float_as_uint(pc.vS[e].x);
             const ulonglong2 jm = pc.jump[j];
-            uint64_t rng = jm.x * pc.rng[slot] + jm.y;
+            uint64_t rng = jm.x * pc.vR[e] + jm.y;
             const float4 m0 = sc.mats[2 * __float_as_uint(P4.w)];
             // Object::bsdf, objects.rs:121-127
             reflected = __float_as_uint(m0.x) == RT_BSDF_DIFFUSE ? scale(mk(m0.y, m0.z, m0.w), 1.0f / RT_PI) : mk(0.0f, 0.0f, 0.0f);
@@ -1348,7 +1350,7 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
         const float4 N4 = pc.vN[e];
         const float4 P4 = pc.vP[e];
         const vec3 p = xyz(P4);
-        const uint64_t rng0 = pc.rng[__float_as_uint(pc.vS[e].x)];
+                const uint64_t rng0 = pc.vR[e];
         // the object the rays start on, fetched once per vertex (see self_blocks())
         const uint32_t self_obj = sc.self_test ? __float_as_uint(N4.w) - 1u : RT_MISS;
         bool self_is_tri = false, self_is_sph = false;
@@ -1724,6 +1726,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SB_WAVES) k_shade_b(DevScene sc, 
         const uint32_t e = e0 + threadIdx.x;
         bool cont = false;
         float4 o_next = make_float4(0, 0, 0, 0), d_next = make_float4(0, 0, 0, 0);
+        uint64_t rng_next = 0ull;
         // whole tiles of 64: the idle lanes of a level's last tile run along on its last vertex (the row masks below are handed from lane to
         // lane, which takes every lane awake) and store nothing
         if ((e & ~63u) < n) {
@@ -1814,7 +1817,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SB_WAVES) k_shade_b(DevScene sc, 
                     fold_path(pc, slot, level, l);                                  // raytracer.rs:340-344
                 } else {
                     const ulonglong2 jm = pc.jump[pc.nlL];
-                    uint64_t rng = jm.x * pc.rng[slot] + jm.y;
+                    uint64_t rng = jm.x * pc.vR[e] + jm.y;
                     if (!(next_f32(&rng) <= RT_ROULETTE)) {                         // weighted_coin_flip, common.rs:136-138
                         fold_path(pc, slot, level, l);
                     } else {
@@ -1834,7 +1837,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SB_WAVES) k_shade_b(DevScene sc, 
                         const float cos_theta = fabsf(dot3(wi, nrm));               // raytracer.rs:321
                         pc.stackA[(size_t)level * pc.npaths + slot] = make_float4(l.x, l.y, l.z, cos_theta);
                         pc.stackB[(size_t)level * pc.npaths + slot] = make_float4(reflected.x, reflected.y, reflected.z, pdf);
-                        pc.rng[slot] = rng;
+                        rng_next = rng;
                         const vec3 dn = unit3(wi);                                  // Ray::new, geo.rs:19-24
                         o_next = make_float4(p.x, p.y, p.z, __uint_as_float(slot));
                         d_next = make_float4(dn.x, dn.y, dn.z, 0.0f);
@@ -1845,7 +1848,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SB_WAVES) k_shade_b(DevScene sc, 
             }
         }
         const uint32_t q = block_append(cont, &pc.counts[level + 1], s_tmp);
-        if (cont) { no[q] = o_next; nd[q] = d_next; }
+        if (cont) { no[q] = o_next; nd[q] = d_next; pc.qrng[(level + 1) & 1][q] = rng_next; }
     }
 }
 
