@@ -98,7 +98,7 @@ struct DevBuf {
 struct Workspace {
     DevBuf<uint32_t> counts, hit_id, blist;
     DevBuf<float> hit_t;
-    DevBuf<float4> ray_o[2], ray_d[2], vP, vN, vS, contrib, direct, stackA, stackB, radiance, lray, linv;
+    DevBuf<float4> ray_o[2], ray_d[2], vP, vN, vS, contrib, direct, stack, radiance, lray, linv;
     DevBuf<uint64_t> rng[3];     // the paths' RNG states: per queued ray (two queues) and per vertex
     DevBuf<unsigned long long> tmask, tmask_t;
     hipStream_t stream = nullptr;   // lanes run on these when there is more than one
@@ -107,7 +107,7 @@ struct Workspace {
     void release() {
         counts.release(); hit_id.release(); blist.release(); hit_t.release();
         for (int q = 0; q < 2; ++q) { ray_o[q].release(); ray_d[q].release(); }
-        vP.release(); vN.release(); vS.release(); contrib.release(); direct.release(); stackA.release(); stackB.release(); radiance.release();
+        vP.release(); vN.release(); vS.release(); contrib.release(); direct.release(); stack.release(); radiance.release();
         lray.release(); linv.release(); for (auto& r : rng) r.release(); tmask.release(); tmask_t.release();
     }
 };
@@ -788,8 +788,7 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
             if (!rc && persist) rc = w.tmask_t.ensure(cap_slots / 64);
             if (!rc && !persist && !in_wave) rc = w.contrib.ensure(cap_paths * (nlL ? nlL : 1));
             if (!rc) rc = w.direct.ensure(persist ? cap_paths * (n_groups ? n_groups : 1) : cap_paths);
-            if (!rc) rc = w.stackA.ensure(per_level);
-            if (!rc) rc = w.stackB.ensure(per_level);
+            if (!rc) rc = w.stack.ensure(2 * per_level);
             if (!rc) rc = w.radiance.ensure(cap_paths);
         }
         if (!rc) break;
@@ -818,7 +817,7 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
         pc.hit_id = w.hit_id.p; pc.hit_t = w.hit_t.p;
         pc.vP = w.vP.p; pc.vN = w.vN.p; pc.qrng[0] = w.rng[0].p; pc.qrng[1] = w.rng[1].p; pc.vR = w.rng[2].p; pc.contrib = w.contrib.p; pc.direct = w.direct.p; pc.in_wave = in_wave ? 1u : 0u;
         pc.lray = w.lray.p; pc.linv = w.linv.p; pc.blist = w.blist.p; pc.tmask = w.tmask.p; pc.tmask_t = w.tmask_t.p; pc.shaft_steps = s->opt_shaft; pc.persist = persist ? 1u : 0u;
-        pc.stackA = w.stackA.p; pc.stackB = w.stackB.p; pc.radiance = w.radiance.p; pc.accum = s->w_accum.p;
+        pc.stack = w.stack.p; pc.stack_depth = P.bounces ? P.bounces : 1; pc.radiance = w.radiance.p; pc.accum = s->w_accum.p;
         pc.jump = s->w_jump.p; pc.stats = s->w_stats.p; pc.rgba = rgba_dev;
         pc.preview = (progress && host_rgba) ? 1u : 0u;
         devs[k] = s->dev;

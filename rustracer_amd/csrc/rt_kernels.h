@@ -120,8 +120,9 @@ struct PassCtx {
                                      // by k_trace_p / k_binary when the ray is occluded: all k_shade_b reads of a ray)
     float4* linv;                    // same places, for the traversal: (1/d of the box test, word: RT_LR_* | occlusion-BVH record of the object the ray starts on)
     uint32_t persist;                // light samples go through k_light + k_trace_p; k_shade_b sums the rays left unblocked in pc.lray
-    float4* stackA;                  // [level][slot] (direct rgb, cos)
-    float4* stackB;                  // [level][slot] (reflected rgb, pdf)
+    float4* stack;                   // [slot][level][2]: (direct rgb, cos), (reflected rgb, pdf): the 32 B of a level in one sector, the levels of a path
+                                     // next to one another (fold_path reads them back in a row; indexed by slot because the queues reorder the paths)
+    uint32_t stack_depth;            // levels per slot (= bounces)
     float4* radiance;                // per path slot: finished sample
     float4* accum;                   // per owned pixel, across sample chunks
     const ulonglong2* jump;          // LCG jump-ahead (mul, add) by 2*j draws, j in [0, nlL]
@@ -859,8 +860,8 @@ __device__ __forceinline__ vec3 mul3(vec3 a, vec3 b) { return mk(a.x * b.x, a.y 
 // radiance by reflected * cos * pdf unless it is black, then add that level's direct term.
 __device__ __forceinline__ void fold_path(const PassCtx& pc, uint32_t slot, uint32_t k, vec3 color) {
     for (uint32_t j = k; j-- > 0;) {
-        const float4 A = pc.stackA[(size_t)j * pc.npaths + slot];
-        const float4 B = pc.stackB[(size_t)j * pc.npaths + slot];
+        const float4* rec = pc.stack + 2 * ((size_t)slot * pc.stack_depth + j);
+        const float4 A = rec[0], B = rec[1];
         if (!spectrum_is_black(color)) color = scale(scale(mul3(color, xyz(B)), A.w), B.w);
         color = add(xyz(A), color);
     }
@@ -1835,8 +1836,9 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SB_WAVES) k_shade_b(DevScene sc, 
                             reflected = scale(refl, 1.0f / fabsf(dot3(wi, nrm)));
                         }
                         const float cos_theta = fabsf(dot3(wi, nrm));               // raytracer.rs:321
-                        pc.stackA[(size_t)level * pc.npaths + slot] = make_float4(l.x, l.y, l.z, cos_theta);
-                        pc.stackB[(size_t)level * pc.npaths + slot] = make_float4(reflected.x, reflected.y, reflected.z, pdf);
+                        float4* rec = pc.stack + 2 * ((size_t)slot * pc.stack_depth + level);
+                        rec[0] = make_float4(l.x, l.y, l.z, cos_theta);
+                        rec[1] = make_float4(reflected.x, reflected.y, reflected.z, pdf);
                         rng_next = rng;
                         const vec3 dn = unit3(wi);                                  // Ray::new, geo.rs:19-24
                         o_next = make_float4(p.x, p.y, p.z, __uint_as_float(slot));
