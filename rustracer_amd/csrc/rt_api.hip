@@ -356,6 +356,7 @@ int upload_scene(rt_scene* s) {
     const HostScene& h = s->host;
     const uint32_t T = h.n_tri(), S = h.n_sph(), M = (uint32_t)h.mats.size();
     const FlatBVH& b = s->bvh;
+    if (M > RT_INFO_MAT) return fail(RT_ERR_LIMIT, "more than 2^30 materials");
 
     int dev_id = 0;
     HIP_TRY(hipGetDevice(&dev_id));
@@ -378,7 +379,9 @@ int upload_scene(rt_scene* s) {
         const vec3 p1 = mk(p[0], p[1], p[2]), p2 = mk(p[3], p[4], p[5]), p3 = mk(p[6], p[7], p[8]);
         const rt_material& m = h.mats[h.tri_mat[i]];
         const bool emissive = !scene_is_black(m.emittance);
-        const uint32_t info = h.tri_mat[i] | (emissive ? 0u : RT_INFO_BLOCKER);
+        const bool flat = (fminf(fminf(p1.x, p2.x), p3.x) == fmaxf(fmaxf(p1.x, p2.x), p3.x)) || (fminf(fminf(p1.y, p2.y), p3.y) == fmaxf(fmaxf(p1.y, p2.y), p3.y)) ||
+                          (fminf(fminf(p1.z, p2.z), p3.z) == fmaxf(fmaxf(p1.z, p2.z), p3.z));
+        const uint32_t info = h.tri_mat[i] | (emissive ? 0u : RT_INFO_BLOCKER) | (flat ? RT_INFO_FLAT : 0u);
         tris[3 * (size_t)i] = make_float4(p1.x, p1.y, p1.z, bits_to_float(b.rank[i]));
         tris[3 * (size_t)i + 1] = make_float4(p2.x, p2.y, p2.z, bits_to_float(info));
         const double e1l = sqrt(((double)p2.x - p1.x) * ((double)p2.x - p1.x) + ((double)p2.y - p1.y) * ((double)p2.y - p1.y) + ((double)p2.z - p1.z) * ((double)p2.z - p1.z));

@@ -38,7 +38,9 @@ namespace rt {
 #define RT_EPS 0.0000001f        // src/common.rs:6
 #define RT_PI 3.14159265358979323846f
 #define RT_ROULETTE 0.7f         // src/raytracer.rs:11
-#define RT_INFO_BLOCKER 0x80000000u
+#define RT_INFO_BLOCKER 0x80000000u   // object info word (tris[3 i + 1].w, sph_aux.y): the object is not emissive, i.e. it blocks is_occluded rays
+#define RT_INFO_FLAT 0x40000000u      // triangle whose box is flat on an axis (a wall): its vertices walk a beam in k_light
+#define RT_INFO_MAT 0x3FFFFFFFu       // material index
 #define RT_HOT 2                // occluders tested in k_light before any traversal, per light
 #define RT_HOT_LIGHTS 4         // lights whose occluder cache travels in k_light's kernel arguments (further lights have none)
 
@@ -1161,7 +1163,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_a(DevScene sc, PassCtx pc, u
             if (id == RT_MISS) {
                 fold_path(pc, slot, level, mk(0.0f, 0.0f, 0.0f));                      // raytracer.rs:348
             } else {
-                const uint32_t mat = object_info(sc, id) & ~RT_INFO_BLOCKER;
+                const uint32_t info = object_info(sc, id);
+                const uint32_t mat = info & RT_INFO_MAT;
                 if (bounces_left == 0) {
                     fold_path(pc, slot, level, xyz(sc.mats[2 * mat + 1]));             // zero_bounce_radiance, raytracer.rs:245-247
                 } else {
@@ -1174,13 +1177,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_a(DevScene sc, PassCtx pc, u
                     vs = make_float4(o4.w, d.x, d.y, d.z);
                     vr = pc.qrng[level & 1][e];
                     alive = true;
-                    if (id >= sc.n_tri) {
-                        cls = 2u;
-                    } else {
-                        const float4* tp = sc.tris + 3 * (size_t)id;
-                        const float4 A = tp[0], B = tp[1], C = tp[2];
-                        cls = (lo3(A.x, B.x, C.x) == hi3(A.x, B.x, C.x) || lo3(A.y, B.y, C.y) == hi3(A.y, B.y, C.y) || lo3(A.z, B.z, C.z) == hi3(A.z, B.z, C.z)) ? 0u : 1u;
-                    }
+                    cls = id >= sc.n_tri ? 2u : ((info & RT_INFO_FLAT) ? 0u : 1u);
                 }
             }
         }
@@ -1234,7 +1231,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SHADOW_WAVES) k_shadow(DevScene s
             if (!HEMI) {
                 const uint32_t light = sc.lights[j / L];
                 const float4 cr = sc.sph[light - sc.n_tri];
-                const vec3 le = xyz(sc.mats[2 * (sc.sph_aux[light - sc.n_tri].y & ~RT_INFO_BLOCKER) + 1]);
+                const vec3 le = xyz(sc.mats[2 * (sc.sph_aux[light - sc.n_tri].y & RT_INFO_MAT) + 1]);
                 const vec3 s = add(xyz(cr), scale(random_sphere(&rng), cr.w));      // Sphere::random_point, objects.rs:223-226
                 const vec3 ps = sub(s, p);
                 d_s = length3(ps);
@@ -1258,7 +1255,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SHADOW_WAVES) k_shadow(DevScene s
             float t;
             traverse<0, STATS>(sc, alive, p, wi, 0.0f, RT_MISS, st, &id, &t, nullptr, &tst);
             if (alive && id != RT_MISS) {
-                const vec3 le = xyz(sc.mats[2 * (object_info(sc, id) & ~RT_INFO_BLOCKER) + 1]);
+                const vec3 le = xyz(sc.mats[2 * (object_info(sc, id) & RT_INFO_MAT) + 1]);
                 const vec3 ch = scale(scale(mul3(le, reflected), cos_theta), 2.0f * RT_PI);
                 out = make_float4(ch.x, ch.y, ch.z, 1.0f);
             }
@@ -1383,8 +1380,7 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
         }
         // Which vertices try a shaft (a choice of where to spend the walk, nothing more): those on a sphere or on a triangle with an axis-flat
         // box (a wall).  A vertex on a mesh triangle has its neighbours in every beam it sends.
-        const bool shaft_vertex = shaft_steps != 0u && (self_is_sph || (self_is_tri && (lo3(A.x, B.x, C.x) == hi3(A.x, B.x, C.x) || lo3(A.y, B.y, C.y) == hi3(A.y, B.y, C.y) ||
-                                                                                         lo3(A.z, B.z, C.z) == hi3(A.z, B.z, C.z))));
+        const bool shaft_vertex = shaft_steps != 0u && (self_is_sph || (self_is_tri && (__float_as_uint(B.w) & RT_INFO_FLAT) != 0u));
         const float own_dnx = (self_is_sph ? A.x - A.w : lo3(A.x, B.x, C.x)) - p.x, own_dny = (self_is_sph ? A.y - A.w : lo3(A.y, B.y, C.y)) - p.y,
                     own_dnz = (self_is_sph ? A.z - A.w : lo3(A.z, B.z, C.z)) - p.z;
         const float own_dxx = (self_is_sph ? A.x + A.w : hi3(A.x, B.x, C.x)) - p.x, own_dxy = (self_is_sph ? A.y + A.w : hi3(A.y, B.y, C.y)) - p.y,
@@ -1444,7 +1440,7 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
           // registers: the vertex adds it right here, in sample order, and the ray leaves no record.  The sum is a chain of f32 additions, so
           // that holds for the samples BEFORE the first one of this (vertex, light) that does leave a record (a k_binary ray); from there on
           // the visible ones go to the row as before and k_shade_b carries on from the sum written below.  Same operations, same order as k_shade_b.
-          const vec3 base = mul3(xyz(sc.mats[2 * (sc.sph_aux[light - sc.n_tri].y & ~RT_INFO_BLOCKER) + 1]), bsdf);
+          const vec3 base = mul3(xyz(sc.mats[2 * (sc.sph_aux[light - sc.n_tri].y & RT_INFO_MAT) + 1]), bsdf);
           const LightPdf lp = light_pdf_setup(p, cr);
           vec3 color = mk(0.0f, 0.0f, 0.0f);
           bool sum_open = clear && pc.light_sum != 0u, has_rec = false;
@@ -1748,7 +1744,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SB_WAVES) k_shade_b(DevScene sc, 
                     for (uint32_t g = 0; g < pc.n_groups; ++g) {
                         const uint32_t light = sc.lights[g];
                         const float4 cr = sc.sph[light - sc.n_tri];
-                        const vec3 le = xyz(sc.mats[2 * (sc.sph_aux[light - sc.n_tri].y & ~RT_INFO_BLOCKER) + 1]);
+                        const vec3 le = xyz(sc.mats[2 * (sc.sph_aux[light - sc.n_tri].y & RT_INFO_MAT) + 1]);
                         const vec3 base = mul3(le, f);
                         const LightPdf lp = light_pdf_setup(p, cr);
                         // the samples k_light summed itself (the leading ones of a clear beam); the rows hold the rest, if any
