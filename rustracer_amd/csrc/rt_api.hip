@@ -156,7 +156,7 @@ struct rt_scene {
 
     bool opt_stats = false, opt_timing = false;
     uint64_t opt_max_paths = 1ull << 25;
-    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 16, opt_phase_bias = 16, opt_shadow_waves = 6, opt_light_waves = 4, opt_hot = 1, opt_extend_persist = 1, opt_extend_refill = 24, opt_extend_inner = 20, opt_extend_grid = 8, opt_lanes = 3, opt_shaft = 8, opt_graze_guard = 0, opt_trace_grid = 8, opt_light_token = 0, opt_light_sum = 1, opt_force_binary = 0;
+    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 16, opt_phase_bias = 16, opt_shadow_waves = 6, opt_light_waves = 4, opt_hot = 1, opt_extend_persist = 1, opt_extend_refill = 24, opt_extend_inner = 20, opt_extend_grid = 8, opt_lanes = 3, opt_shaft = 8, opt_graze_guard = 0, opt_trace_grid = 8, opt_light_token = 0, opt_light_sum = 1, opt_force_binary = 0, opt_camera_once = 1;
     uint64_t opt_lane_min_pixels = 65536;
     uint64_t opt_fail_after_passes = 0;          // test hook: render_impl reports a failure once this many passes are enqueued (0 = never)
     uint32_t grid_max = 2048;
@@ -857,6 +857,7 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
             return fail(RT_ERR_INTERRUPTED, "render interrupted");
         }
         bool active[RT_MAX_LANES] = {false, false, false, false};
+        bool camera_once[RT_MAX_LANES] = {false, false, false, false};
         // a round: one pass per lane, enqueued level by level across the lanes (lane 0's level l, lane 1's level l, ..., then level l + 1), so that the
         // k_light launches of the lanes can be chained (light_token below)
         for (uint32_t k = 0; k < n_lanes; ++k) {
@@ -874,9 +875,19 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
             HIP_TRY(hipMemsetAsync(pc.counts, 0, 3 * (levels + 1) * sizeof(uint32_t), st));
             size_t ev;
             active[k] = true;
-            begin_timing(s, st, 2, &ev);
-            hipLaunchKernelGGL(k_generate, dim3(grid_for(s, pc.npaths)), dim3(RT_BLOCK), 0, st, pc);
-            end_timing(s, st, ev);
+            // the camera rays: one traversal per pixel serves the pass's samples of that pixel (k_camera), unless they are to go through the
+            // persistent k_extend_p ("extend_persist" 2) or the scene is empty
+            camera_once[k] = s->opt_camera_once && s->opt_extend_persist <= 1;
+            if (camera_once[k]) {
+                begin_timing(s, st, 0, &ev);
+                if (s->opt_stats) hipLaunchKernelGGL(k_camera<true>, dim3(grid_for(s, npix)), dim3(RT_BLOCK), 0, st, devs[k], pc);
+                else hipLaunchKernelGGL(k_camera<false>, dim3(grid_for(s, npix)), dim3(RT_BLOCK), 0, st, devs[k], pc);
+                end_timing(s, st, ev);
+            } else {
+                begin_timing(s, st, 2, &ev);
+                hipLaunchKernelGGL(k_generate, dim3(grid_for(s, pc.npaths)), dim3(RT_BLOCK), 0, st, pc);
+                end_timing(s, st, ev);
+            }
         }
         for (uint32_t level = 0; level < levels; ++level) {
           for (uint32_t k = 0; k < n_lanes; ++k) {
@@ -893,8 +904,9 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
                     if (*interrupt) return fail(RT_ERR_INTERRUPTED, "render interrupted");
                 }
                 const uint32_t g = grid_for(s, pc.npaths);
-                begin_timing(s, st, 0, &ev);
-                if (s->opt_extend_persist && (level > 0 || s->opt_extend_persist > 1)) {
+                if (level == 0 && camera_once[k]) {
+                    ev = (size_t)-1;           // traced by k_camera
+                } else if (begin_timing(s, st, 0, &ev), s->opt_extend_persist && (level > 0 || s->opt_extend_persist > 1)) {
                     // after the first bounce: persistent waves that refill their idle lanes (k_extend_p); camera rays are coherent and stay with k_extend
                     uint32_t gp = s->grid_max / 8u * s->opt_extend_grid;
                     if (gp > g) gp = g;
@@ -1348,6 +1360,7 @@ int rt_set_option(rt_scene* s, const char* name, uint64_t value) {
     else if (n == "graze_guard") { s->opt_graze_guard = value ? 1 : 0; s->dev.graze_guard = s->opt_graze_guard; }
     else if (n == "fail_after_passes") s->opt_fail_after_passes = value;
     else if (n == "light_sum") s->opt_light_sum = value ? 1 : 0;
+    else if (n == "camera_once") s->opt_camera_once = value ? 1 : 0;
     else if (n == "force_binary") s->opt_force_binary = (uint32_t)value;
     else if (n == "shaft") s->opt_shaft = value > RT_STACK_LDS ? RT_STACK_LDS : (uint32_t)value;
     else if (n == "inner_min") { s->opt_inner_min = value > 64 ? 64 : (uint32_t)value; s->dev.inner_min = s->opt_inner_min; }
@@ -1363,7 +1376,7 @@ int rt_get_option(const rt_scene* s, const char* name, uint64_t* value) {
         {"persist", s->opt_persist}, {"hot", s->opt_hot}, {"shadow_waves", s->opt_shadow_waves}, {"light_waves", s->opt_light_waves},
         {"refill_min", s->opt_refill_min}, {"phase_bias", s->opt_phase_bias}, {"inner_min", s->opt_inner_min}, {"lanes", s->opt_lanes},
         {"lane_min_pixels", s->opt_lane_min_pixels}, {"extend_persist", s->opt_extend_persist}, {"extend_refill", s->opt_extend_refill},
-        {"extend_inner", s->opt_extend_inner}, {"extend_grid", s->opt_extend_grid}, {"shaft", s->opt_shaft}, {"trace_grid", s->opt_trace_grid}, {"light_token", s->opt_light_token}, {"graze_guard", s->opt_graze_guard}, {"light_sum", s->opt_light_sum}, {"force_binary", s->opt_force_binary}};
+        {"extend_inner", s->opt_extend_inner}, {"extend_grid", s->opt_extend_grid}, {"shaft", s->opt_shaft}, {"trace_grid", s->opt_trace_grid}, {"light_token", s->opt_light_token}, {"graze_guard", s->opt_graze_guard}, {"light_sum", s->opt_light_sum}, {"camera_once", s->opt_camera_once}, {"force_binary", s->opt_force_binary}};
     for (const auto& e : table)
         if (n == e.name) { *value = e.v; return RT_OK; }
     return fail(RT_ERR_INVALID, "unknown option '" + n + "'");

@@ -875,10 +875,11 @@ __device__ __forceinline__ void fold_path(const PassCtx& pc, uint32_t slot, uint
 // queue (same-address atomics retire at roughly 10 ns each on MI355X, so one per wave made
 // k_generate / k_shade_* atomic-bound: profiles/r01_v3).  Every thread of the workgroup must call
 // it the same number of times.  s_tmp: RT_BLOCK / 64 + 1 words.
-__device__ __forceinline__ uint32_t block_append(bool keep, uint32_t* counter, uint32_t* s_tmp) {
+// `each`: queue entries per kept thread (k_camera reserves a run per pixel); the return value is the first of them.
+__device__ __forceinline__ uint32_t block_append(bool keep, uint32_t* counter, uint32_t* s_tmp, uint32_t each = 1u) {
     const unsigned long long mask = __ballot(keep);
     const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
-    if (lane == 0) s_tmp[wave] = (uint32_t)__popcll(mask);
+    if (lane == 0) s_tmp[wave] = (uint32_t)__popcll(mask) * each;
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t total = 0;
@@ -889,7 +890,7 @@ __device__ __forceinline__ uint32_t block_append(bool keep, uint32_t* counter, u
     uint32_t base = s_tmp[RT_BLOCK / 64];
     for (uint32_t w = 0; w < wave; ++w) base += s_tmp[w];
     __syncthreads();
-    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)) * each;
 }
 
 // block_append that also groups what it appends by a class 0..2: within the workgroup's run the entries of class 0 come first, then class 1, then
@@ -1026,6 +1027,60 @@ __global__ void __launch_bounds__(RT_BLOCK, 8) k_extend(DevScene sc, PassCtx pc,
     }
     flush_stats<STATS>(pc.stats, tst, ST_C_INNER);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&pc.stats[ST_RAYS_CLOSEST], (unsigned long long)n);
+}
+
+// k_generate + k_extend for the camera rays of a pass in one kernel: every sample of a pixel starts with the same primary ray
+// (render_helper casts screen_to_world(i, j) spp times, raytracer.rs:224-235), so the ray is traced once per pixel and its hit handed to the
+// pixel's spc samples of the pass, which differ in their path slot and RNG stream only.  A wave's pixels reserve consecutive runs of spc queue
+// entries, so the wave writes one contiguous stretch of the queue, 64 entries at a time.  The reference's spc intersect calls are counted as
+// such (ST_RAYS_CLOSEST); the traversal counters ("stats") count the work done, i.e. one traversal per pixel.
+template <bool STATS>
+__global__ void __launch_bounds__(RT_BLOCK, 8) k_camera(DevScene sc, PassCtx pc) {
+    RT_STACK_DECL;
+    TravStats tst = {0, 0, 0, 0, 0};
+    const rt_render_params& P = pc.P;
+    const vec3 cam = mk(P.cam[0], P.cam[1], P.cam[2]);
+    __shared__ uint32_t s_tmp[RT_BLOCK / 64 + 1];
+    __shared__ uint32_t s_lane[RT_BLOCK];              // per wave: the lane of its r-th valid pixel
+    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6, spc = pc.spc;
+    uint32_t n_entries = 0;
+    for (uint32_t pl0 = blockIdx.x * RT_BLOCK; pl0 < pc.npix; pl0 += gridDim.x * RT_BLOCK) {
+        const uint32_t pl = pl0 + threadIdx.x;
+        uint32_t x = 0, y = 0, id = RT_MISS;
+        float t = 0.0f;
+        vec3 d = mk(0.0f, 0.0f, 1.0f);
+        const bool valid = pl < pc.npix && own_pixel_xy(P, pc.tiles_x, pc.pix0 + pl, &x, &y);
+        if (valid) d = screen_to_world(P, x, y);
+        traverse<0, STATS>(sc, valid, cam, d, 0.0f, RT_MISS, st, &id, &t, nullptr, &tst);
+        const unsigned long long m = __ballot(valid);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (valid) s_lane[wave * 64u + rank] = lane;
+        const uint32_t q0 = block_append(valid, &pc.counts[0], s_tmp, spc);       // this pixel's run of spc entries (barriers inside: s_lane is visible)
+        const uint32_t total = (uint32_t)__popcll(m) * spc;
+        if (total == 0u) continue;
+        const uint32_t wave_base = (uint32_t)__shfl((int)q0, __ffsll((long long)m) - 1);
+        n_entries += lane == 0u ? total : 0u;
+        for (uint32_t i0 = 0; i0 < total; i0 += 64u) {                                // every lane stays in the loop: the hits are handed over by __shfl
+            const uint32_t i = i0 + lane;
+            const bool mine = i < total;
+            const uint32_t r = mine ? i / spc : 0u, k = i - r * spc;
+            const int src = (int)s_lane[wave * 64u + r];
+            const uint32_t pl_s = (uint32_t)__shfl((int)pl, src), x_s = (uint32_t)__shfl((int)x, src), y_s = (uint32_t)__shfl((int)y, src);
+            const uint32_t id_s = (uint32_t)__shfl((int)id, src);
+            const float t_s = __shfl(t, src), dx = __shfl(d.x, src), dy = __shfl(d.y, src), dz = __shfl(d.z, src);
+            if (mine) {
+                const uint32_t e = wave_base + i, slot = pl_s * spc + k;
+                pc.qrng[0][e] = stream_seed(pc.seed_mixed, y_s * P.width + x_s, pc.s0 + k);
+                pc.ray_o[0][e] = make_float4(cam.x, cam.y, cam.z, __uint_as_float(slot));
+                pc.ray_d[0][e] = make_float4(dx, dy, dz, 0.0f);
+                pc.hit_id[e] = id_s;
+                pc.hit_t[e] = t_s;
+            }
+        }
+    }
+    flush_stats<STATS>(pc.stats, tst, ST_C_INNER);
+    const uint32_t t_entries = block_sum_to_thread0(n_entries, s_tmp);
+    if (threadIdx.x == 0 && t_entries) atomicAdd(&pc.stats[ST_RAYS_CLOSEST], (unsigned long long)t_entries);
 }
 
 // Scene::intersect for the ray queue as a persistent wave loop: the traversal of traverse<0> (same tree, same tests, same pruning and
