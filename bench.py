@@ -195,7 +195,7 @@ def main():
 
     # ---- roofline of the dominant kernel ----
     # Three kernels carry the frame: k_light (Object::sample_l + the occluder-cache tests, one thread per path vertex looping over the
-    # light samples), k_trace_p (Scene::is_occluded for the survivors) and k_extend (Scene::intersect).  Each gets its algorithmic
+    # light samples), k_trace_p (Scene::is_occluded for the survivors) and k_extend_p (Scene::intersect).  Each gets its algorithmic
     # bytes per launch over its HIP-event launch time; `roofline` is the one with the largest share of the frame.
     roofline = None
     traced_shadow_per_step = None
@@ -260,7 +260,7 @@ def main():
         b_ext = (64.0 * sc["closest_inner"] + 48.0 * sc["closest_tris"] + 16.0 * sc["closest_sphs"]) / n_closest + 48.0 \
             + (80.0 * sc["closest_hits_tri"] + 32.0 * sc["closest_hits_sph"]) / n_closest
         kernels["k_extend_p"] = {
-            "what": "Scene::intersect: closest hit on the binary SAH tree (while-while, rank tie-break): k_extend for the camera rays, the persistent "
+            "what": "Scene::intersect: closest hit on the binary SAH tree (while-while, rank tie-break): k_camera for the camera rays (one traversal per pixel and pass), the persistent "
                     "k_extend_p with lane refill after the first bounce (8 of 9 launches; the PMC figures are k_extend_p's)",
             "unit": "intersect ray", "bytes_per_unit": round(b_ext, 1), "units_per_launch": round(cnt["rays_closest"] / max(cnt["launches_closest"], 1), 1),
             "launches_per_step": int(cnt["launches_closest"]), "ms_per_step": round(cnt["kernel_ms_closest"], 2)}
@@ -330,7 +330,7 @@ def main():
                             "static class mix of its loop x the per-class issue cost measured by tools/valu_rate.hip, profiles/r02_valu_rate.txt)",
             "kernels": kernels,
             "kernel_ms_per_step_one_lane": {"k_light": round(ex["kernel_ms_light"], 2), "k_trace_p": round(ex["kernel_ms_shadow"], 2),
-                                            "k_extend+k_extend_p": round(ex["kernel_ms_closest"], 2), "shade+generate+resolve+k_binary": round(ex["kernel_ms_shade"], 2)},
+                                            "k_camera+k_extend_p": round(ex["kernel_ms_closest"], 2), "shade+resolve+k_binary": round(ex["kernel_ms_shade"], 2)},
             "note": "The scene (%.0f MB) is resident in L2 / Infinity Cache: most algorithmic bytes of the traversal kernels (BVH nodes, primitive records) are "
                     "served on-die, so their `achieved` can exceed what HBM delivers; `traffic` is what crossed the fabric" % (scene.info.device_bytes / 1e6),
         }

@@ -2,8 +2,10 @@
 //
 // One pass renders `npaths` camera samples in lock step.  Per bounce level k (bounces_left =
 // bounces - k, src/raytracer.rs:330-350) the host enqueues
-//   k_extend / k_extend_p  closest-hit BVH traversal over the live ray queue (Scene::intersect, mod.rs:406-447): camera rays / the
-//              rays after the first bounce, the latter in persistent waves that hand new rays to finished lanes
+//   k_camera   (level 0) the camera ray of every pixel of the pass, traced once and handed to the pixel's samples of the pass: ray queue,
+//              RNG streams and hits in one kernel (render_helper, raytracer.rs:224-235; k_generate + k_extend with option "camera_once" 0)
+//   k_extend_p closest-hit BVH traversal over the live ray queue after the first bounce (Scene::intersect, mod.rs:406-447), in persistent
+//              waves that hand new rays to finished lanes (k_extend: one ray per thread, option "extend_persist" 0)
 //   k_shade_a  hit point + shading normal, terminates misses / depth 0 (mod.rs:58-67, raytracer.rs:339)
 //   k_light    one thread per vertex over its lights x light samples: Object::sample_l's point and ray (objects.rs:96-108) and the
 //              is_occluded tests that need no traversal (the object the ray starts on, the light's occluder cache); the rays it

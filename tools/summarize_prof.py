@@ -26,19 +26,19 @@ def valu_busy(a):
 
 
 def per_bounce(per_disp):
-    """k_extend / k_light / k_trace_p run once per path level (bounce) and pass, in level order: dispatch i of a kernel is level i mod levels."""
+    """k_extend_p / k_light / k_trace_p run once per path level (bounce) and pass, in level order: dispatch i of a kernel is level i mod levels."""
     out = ["## Per bounce (level = dispatch index modulo the launches per pass; sums over the passes of the run)", "",
            "| kernel | level | waves | VALU instructions | active lanes | VALU issue busy |", "|---|---|---|---|---|---|"]
     for k in sorted(per_disp):
         base = k.split("<")[0]
-        if base not in ("k_extend", "k_light", "k_trace_p"):
+        if base not in ("k_extend_p", "k_light", "k_trace_p"):
             continue
         d = per_disp[k]
         need = ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "GRBM_GUI_ACTIVE")
         if any(c not in d for c in need):
             continue
         n = len(d["SQ_WAVES"])
-        per_pass = 9 if base == "k_extend" else 8
+        per_pass = 8
         if n % per_pass:
             continue
         rows = defaultdict(lambda: defaultdict(float))
