@@ -25,9 +25,10 @@ def valu_busy(a):
     return a.get("SQ_ACTIVE_INST_VALU", 0) * 4.0 / max(N_SIMD * a.get("GRBM_GUI_ACTIVE", 0) / N_XCD, 1)
 
 
-def per_bounce(per_disp):
-    """k_extend_p / k_light / k_trace_p run once per path level (bounce) and pass, in level order: dispatch i of a kernel is level i mod levels."""
-    out = ["## Per bounce (level = dispatch index modulo the launches per pass; sums over the passes of the run)", "",
+def per_bounce(per_disp, lanes=1):
+    """k_extend_p / k_light / k_trace_p run once per path level (bounce) and pass; a round of `lanes` passes is enqueued level by level across the
+    lanes (lane 0's level l, lane 1's, ..., then level l + 1), so dispatch i of a kernel is level (i div lanes) mod levels."""
+    out = ["## Per bounce (level = (dispatch index div %d render lanes) modulo the launches per pass; sums over the passes of the run)" % lanes, "",
            "| kernel | level | waves | VALU instructions | active lanes | VALU issue busy |", "|---|---|---|---|---|---|"]
     for k in sorted(per_disp):
         base = k.split("<")[0]
@@ -39,12 +40,12 @@ def per_bounce(per_disp):
             continue
         n = len(d["SQ_WAVES"])
         per_pass = 8
-        if n % per_pass:
+        if n % (per_pass * lanes):
             continue
         rows = defaultdict(lambda: defaultdict(float))
         for c in need:
             for i, (_, v) in enumerate(sorted(d[c])):
-                rows[i % per_pass][c] += v
+                rows[(i // lanes) % per_pass][c] += v
         for lv in range(per_pass):
             r = rows[lv]
             out.append("| `%s` | %d | %d | %.4g | %.3f | %.3f |" % (k, lv, r["SQ_WAVES"], r["SQ_INSTS_VALU"],
@@ -104,7 +105,11 @@ def main(src, dst):
                 "instruction.  'VALU issue busy' = 4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE / 8): the fraction of all SIMD cycles of the kernel's "
                 "run time in which the SIMD's VALU was executing (a wave64 instruction occupies its SIMD's 16-lane VALU for 4 cycles; counters of different "
                 "passes come from different runs, so a ratio can exceed 1 by a few percent).  'waves resident' = 4 * SQ_WAVE_CYCLES over the same denominator.", ""]
-        out += per_bounce(per_disp)
+        lanes = 1
+        for line in (open(os.path.join(src, "trace.log")) if os.path.exists(os.path.join(src, "trace.log")) else []):
+            if line.startswith("{"):
+                lanes = int((json.loads(line).get("config") or {}).get("render_lanes") or 1)
+        out += per_bounce(per_disp, lanes)
     os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
     open(dst, "w").write("\n".join(out) + "\n")
     print("\n".join(out))
