@@ -1758,9 +1758,9 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
 }
 
 // The rest of one_bounce_radiance_importance and global_illumination (src/raytracer.rs:282-326).
-// k_shade_b waits on memory (VALU 0.36 busy): 8 resident waves per SIMD (a 64-register budget, 36 B of spills) with 2 light-sample records in
-// flight per lane; measured per 32-spp frame of config 4, one lane: 2 in flight 39.2 ms of shading kernels, 1: 46.5, 3: 40.0, 4: 41.0;
-// 6 waves: 45.0, 5 waves with 8 in flight: 44.2.
+// k_shade_b waits on memory (84 % of its wave cycles): 8 resident waves per SIMD (a 64-register budget, 60 B of spills) with 2 light-sample
+// records in flight per lane (round 2, when it read 27 % of the light samples back: 1 in flight + 19 %, 3: + 2 %, 4: + 5 %, 6 waves + 15 %; now
+// that it reads 4 %, 3 or 4 in flight or 6 waves change nothing).  What it waits for is the path bookkeeping, scattered by path slot.
 #ifndef RT_SB_WAVES
 #define RT_SB_WAVES 8
 #endif
@@ -1864,41 +1864,41 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SB_WAVES) k_shade_b(DevScene sc, 
                 // (what only the rest needs is fetched here, after the sample loop: k_shade_b waits on memory, and registers held across
                 // the loop cost it resident waves)
                 if (live) {
-                const float4 S4 = pc.vS[e], m1 = sc.mats[2 * mat + 1];
-                const uint32_t slot = __float_as_uint(S4.x);
-                l = add(l, xyz(m1));                                                // raytracer.rs:284
-                if (bounces_left == 1) {
-                    fold_path(pc, slot, level, l);                                  // raytracer.rs:340-344
-                } else {
-                    const ulonglong2 jm = pc.jump[pc.nlL];
-                    uint64_t rng = jm.x * pc.vR[e] + jm.y;
-                    if (!(next_f32(&rng) <= RT_ROULETTE)) {                         // weighted_coin_flip, common.rs:136-138
-                        fold_path(pc, slot, level, l);
+                    const float4 S4 = pc.vS[e], m1 = sc.mats[2 * mat + 1];
+                    const uint32_t slot = __float_as_uint(S4.x);
+                    l = add(l, xyz(m1));                                                // raytracer.rs:284
+                    if (bounces_left == 1) {
+                        fold_path(pc, slot, level, l);                                  // raytracer.rs:340-344
                     } else {
-                        const vec3 wo = mk(S4.y, S4.z, S4.w);
-                        vec3 wi, reflected;
-                        float pdf;
-                        const vec3 refl = mk(m0.y, m0.z, m0.w);
-                        if (__float_as_uint(m0.x) == RT_BSDF_DIFFUSE) {             // Object::sample_bsdf, objects.rs:130-148
-                            wi = to_coord_space(random_hemisphere(&rng), nrm);
-                            pdf = 2.0f * RT_PI;
-                            reflected = scale(refl, 1.0f / RT_PI);
+                        const ulonglong2 jm = pc.jump[pc.nlL];
+                        uint64_t rng = jm.x * pc.vR[e] + jm.y;
+                        if (!(next_f32(&rng) <= RT_ROULETTE)) {                         // weighted_coin_flip, common.rs:136-138
+                            fold_path(pc, slot, level, l);
                         } else {
-                            wi = sub(wo, scale(scale(nrm, 2.0f), dot3(wo, nrm)));
-                            pdf = 1.0f;
-                            reflected = scale(refl, 1.0f / fabsf(dot3(wi, nrm)));
+                            const vec3 wo = mk(S4.y, S4.z, S4.w);
+                            vec3 wi, reflected;
+                            float pdf;
+                            const vec3 refl = mk(m0.y, m0.z, m0.w);
+                            if (__float_as_uint(m0.x) == RT_BSDF_DIFFUSE) {             // Object::sample_bsdf, objects.rs:130-148
+                                wi = to_coord_space(random_hemisphere(&rng), nrm);
+                                pdf = 2.0f * RT_PI;
+                                reflected = scale(refl, 1.0f / RT_PI);
+                            } else {
+                                wi = sub(wo, scale(scale(nrm, 2.0f), dot3(wo, nrm)));
+                                pdf = 1.0f;
+                                reflected = scale(refl, 1.0f / fabsf(dot3(wi, nrm)));
+                            }
+                            const float cos_theta = fabsf(dot3(wi, nrm));               // raytracer.rs:321
+                            float4* rec = pc.stack + 2 * ((size_t)slot * pc.stack_depth + level);
+                            rec[0] = make_float4(l.x, l.y, l.z, cos_theta);
+                            rec[1] = make_float4(reflected.x, reflected.y, reflected.z, pdf);
+                            rng_next = rng;
+                            const vec3 dn = unit3(wi);                                  // Ray::new, geo.rs:19-24
+                            o_next = make_float4(p.x, p.y, p.z, __uint_as_float(slot));
+                            d_next = make_float4(dn.x, dn.y, dn.z, 0.0f);
+                            cont = true;
                         }
-                        const float cos_theta = fabsf(dot3(wi, nrm));               // raytracer.rs:321
-                        float4* rec = pc.stack + 2 * ((size_t)slot * pc.stack_depth + level);
-                        rec[0] = make_float4(l.x, l.y, l.z, cos_theta);
-                        rec[1] = make_float4(reflected.x, reflected.y, reflected.z, pdf);
-                        rng_next = rng;
-                        const vec3 dn = unit3(wi);                                  // Ray::new, geo.rs:19-24
-                        o_next = make_float4(p.x, p.y, p.z, __uint_as_float(slot));
-                        d_next = make_float4(dn.x, dn.y, dn.z, 0.0f);
-                        cont = true;
                     }
-                }
                 }
             }
         }
