@@ -180,6 +180,7 @@ int rt_get_counters(const rt_scene* scene, rt_counters* out);
  *   order, and writes no record for them (0: every visible ray leaves a record for k_shade_b);
  *   "refill_min" (16), "phase_bias" (16), "shadow_waves" (6), "light_waves" (4), "inner_min" (12), "extend_refill" (24),
  *   "extend_inner" (20), "extend_grid" (8 workgroups per CU): scheduling constants;
+ *   "light_grid" n (default 0 = no limit): at most n k_light workgroups per CU (8 = the resident size; one workgroup per 256 vertices otherwise);
  *   "light_token" 0/1 (default 0): the lanes' k_light launches wait for one another (measured slower); "trace_grid" (8): k_trace_p workgroups per CU
  *   in eighths of its resident capacity;
  *   "graze_guard" 0/1 (default 0): a Scene::intersect ray that tests a triangle lying within about 2^-10 rad of it stops skipping subtrees by

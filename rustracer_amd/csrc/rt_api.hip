@@ -156,7 +156,7 @@ struct rt_scene {
 
     bool opt_stats = false, opt_timing = false;
     uint64_t opt_max_paths = 1ull << 25;
-    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 16, opt_phase_bias = 16, opt_shadow_waves = 6, opt_light_waves = 4, opt_hot = 1, opt_extend_persist = 1, opt_extend_refill = 24, opt_extend_inner = 20, opt_extend_grid = 8, opt_lanes = 3, opt_shaft = 8, opt_graze_guard = 0, opt_trace_grid = 8, opt_light_token = 0, opt_light_sum = 1, opt_force_binary = 0, opt_camera_once = 1;
+    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 16, opt_phase_bias = 16, opt_shadow_waves = 6, opt_light_waves = 4, opt_hot = 1, opt_extend_persist = 1, opt_extend_refill = 24, opt_extend_inner = 20, opt_extend_grid = 8, opt_lanes = 3, opt_shaft = 8, opt_graze_guard = 0, opt_trace_grid = 8, opt_light_token = 0, opt_light_sum = 1, opt_force_binary = 0, opt_camera_once = 1, opt_light_grid = 0;
     uint64_t opt_lane_min_pixels = 65536;
     uint64_t opt_fail_after_passes = 0;          // test hook: render_impl reports a failure once this many passes are enqueued (0 = never)
     uint32_t grid_max = 2048;
@@ -926,11 +926,17 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
                         // "light_token" (off: measured slower, 134.1 vs 127.2 ms per 32-spp frame with three lanes, 140.2 vs 131.8 with two): chain the
                         // k_light launches of the lanes through events, lane after lane and level after level, so that no two of them share the GPU
                         if (token && last_light) HIP_TRY(hipStreamWaitEvent(st, last_light, 0));
-                        if (s->opt_stats) hipLaunchKernelGGL((k_light<true, 4>), dim3(g), dim3(RT_BLOCK), 0, st, dv, pc, level, s->hot_table);
-                        else if (s->opt_light_waves >= 8) hipLaunchKernelGGL((k_light<false, 8>), dim3(g), dim3(RT_BLOCK), 0, st, dv, pc, level, s->hot_table);
-                        else if (s->opt_light_waves >= 6) hipLaunchKernelGGL((k_light<false, 6>), dim3(g), dim3(RT_BLOCK), 0, st, dv, pc, level, s->hot_table);
-                        else if (s->opt_light_waves >= 5) hipLaunchKernelGGL((k_light<false, 5>), dim3(g), dim3(RT_BLOCK), 0, st, dv, pc, level, s->hot_table);
-                        else hipLaunchKernelGGL((k_light<false, 4>), dim3(g), dim3(RT_BLOCK), 0, st, dv, pc, level, s->hot_table);
+                        // k_light: one workgroup per 256 vertices, however many that makes ("light_grid" 0; n: at most n per CU).  Its vertices differ
+                        // several-fold in cost (beam walk or not, which arm of the own-object test), and with a grid of resident size and a fixed share
+                        // each, the workgroups finished far apart: 73.6 vs 66.5 ms per 32-spp frame, one lane.  The hardware's dispatcher does the balancing.
+                        uint32_t gl = (uint32_t)(((uint64_t)pc.npaths + RT_BLOCK - 1) / RT_BLOCK);
+                        if (s->opt_light_grid && gl > s->grid_max / 8u * s->opt_light_grid) gl = s->grid_max / 8u * s->opt_light_grid;
+                        if (gl < 1u) gl = 1u;
+                        if (s->opt_stats) hipLaunchKernelGGL((k_light<true, 4>), dim3(gl), dim3(RT_BLOCK), 0, st, dv, pc, level, s->hot_table);
+                        else if (s->opt_light_waves >= 8) hipLaunchKernelGGL((k_light<false, 8>), dim3(gl), dim3(RT_BLOCK), 0, st, dv, pc, level, s->hot_table);
+                        else if (s->opt_light_waves >= 6) hipLaunchKernelGGL((k_light<false, 6>), dim3(gl), dim3(RT_BLOCK), 0, st, dv, pc, level, s->hot_table);
+                        else if (s->opt_light_waves >= 5) hipLaunchKernelGGL((k_light<false, 5>), dim3(gl), dim3(RT_BLOCK), 0, st, dv, pc, level, s->hot_table);
+                        else hipLaunchKernelGGL((k_light<false, 4>), dim3(gl), dim3(RT_BLOCK), 0, st, dv, pc, level, s->hot_table);
                         end_timing(s, st, ev);
                         if (token) { HIP_TRY(hipEventRecord(s->ws[k].light, st)); last_light = s->ws[k].light; }
                         begin_timing(s, st, 2, &ev);
@@ -1361,6 +1367,7 @@ int rt_set_option(rt_scene* s, const char* name, uint64_t value) {
     else if (n == "fail_after_passes") s->opt_fail_after_passes = value;
     else if (n == "light_sum") s->opt_light_sum = value ? 1 : 0;
     else if (n == "camera_once") s->opt_camera_once = value ? 1 : 0;
+    else if (n == "light_grid") s->opt_light_grid = (uint32_t)value;
     else if (n == "force_binary") s->opt_force_binary = (uint32_t)value;
     else if (n == "shaft") s->opt_shaft = value > RT_STACK_LDS ? RT_STACK_LDS : (uint32_t)value;
     else if (n == "inner_min") { s->opt_inner_min = value > 64 ? 64 : (uint32_t)value; s->dev.inner_min = s->opt_inner_min; }
@@ -1376,7 +1383,7 @@ int rt_get_option(const rt_scene* s, const char* name, uint64_t* value) {
         {"persist", s->opt_persist}, {"hot", s->opt_hot}, {"shadow_waves", s->opt_shadow_waves}, {"light_waves", s->opt_light_waves},
         {"refill_min", s->opt_refill_min}, {"phase_bias", s->opt_phase_bias}, {"inner_min", s->opt_inner_min}, {"lanes", s->opt_lanes},
         {"lane_min_pixels", s->opt_lane_min_pixels}, {"extend_persist", s->opt_extend_persist}, {"extend_refill", s->opt_extend_refill},
-        {"extend_inner", s->opt_extend_inner}, {"extend_grid", s->opt_extend_grid}, {"shaft", s->opt_shaft}, {"trace_grid", s->opt_trace_grid}, {"light_token", s->opt_light_token}, {"graze_guard", s->opt_graze_guard}, {"light_sum", s->opt_light_sum}, {"camera_once", s->opt_camera_once}, {"force_binary", s->opt_force_binary}};
+        {"extend_inner", s->opt_extend_inner}, {"extend_grid", s->opt_extend_grid}, {"shaft", s->opt_shaft}, {"trace_grid", s->opt_trace_grid}, {"light_token", s->opt_light_token}, {"graze_guard", s->opt_graze_guard}, {"light_sum", s->opt_light_sum}, {"camera_once", s->opt_camera_once}, {"light_grid", s->opt_light_grid}, {"force_binary", s->opt_force_binary}};
     for (const auto& e : table)
         if (n == e.name) { *value = e.v; return RT_OK; }
     return fail(RT_ERR_INVALID, "unknown option '" + n + "'");

@@ -271,14 +271,14 @@ def test_occluder_cache_and_scheduling_switches_do_not_change_a_pixel(gpu):
     for opts in ({}, {"self_test": 0}, {"refill_min": 1, "phase_bias": 1}, {"refill_min": 64, "phase_bias": 4, "shadow_waves": 5},
                  {"light_waves": 8}, {"extend_persist": 0}, {"extend_persist": 2, "extend_refill": 1, "extend_inner": 1},
                  {"extend_persist": 2, "extend_refill": 64, "extend_inner": 64, "extend_grid": 1}, {"extend_refill": 7, "extend_inner": 40, "extend_grid": 3},
-                 {"shaft": 0}, {"shaft": 1}, {"shaft": 3, "refill_min": 1}, {"shaft": 16}, {"camera_once": 0}, {"camera_once": 0, "light_sum": 0, "extend_persist": 0}):
+                 {"shaft": 0}, {"shaft": 1}, {"shaft": 3, "refill_min": 1}, {"shaft": 16}, {"camera_once": 0}, {"camera_once": 0, "light_sum": 0, "extend_persist": 0}, {"light_grid": 8}, {"light_grid": 1, "trace_grid": 1}):
         for k, v in opts.items():
             gsc.set_option(k, v)
         got, cnt = gpu_render(gsc, p)
         assert np.array_equal(got, ref["rgba"]), opts
         assert cnt["rays_shadow"] == ref["occluded_calls"] and cnt["rays_closest"] == ref["intersect_calls"], opts
         for k, v in {"self_test": 1, "refill_min": 16, "phase_bias": 16, "shadow_waves": 6, "light_waves": 4, "extend_persist": 1, "extend_refill": 24,
-                     "extend_inner": 20, "extend_grid": 8, "shaft": 8, "camera_once": 1, "light_sum": 1}.items():
+                     "extend_inner": 20, "extend_grid": 8, "shaft": 8, "camera_once": 1, "light_sum": 1, "light_grid": 0, "trace_grid": 8}.items():
             gsc.set_option(k, v)
     with pytest.raises(Exception):
         gsc.set_option("hot", 0)                           # the cache is chosen at the first render
