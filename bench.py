@@ -327,7 +327,8 @@ def main():
             "compute": d.get("compute"),
             "compute_note": "the kernel is bound by VALU instruction issue, not by HBM: `compute` sets its measured wave64 VALU instruction rate (SQ_INSTS_VALU "
                             "per unit from the PMC passes x units / launch time) against the issue ceiling of its instruction mix (profiles/r*_isa_mix.json: "
-                            "static class mix of its loop x the per-class issue cost measured by tools/valu_rate.hip, profiles/r02_valu_rate.txt)",
+                            "static class mix of its loop; every non-transcendental instruction at the fast class's issue cost unless the slow class alone "
+                            "takes longer, transcendentals added in full: the mixed-stream rows of tools/valu_rate.hip, profiles/r02_valu_rate.txt)",
             "kernels": kernels,
             "kernel_ms_per_step_one_lane": {"k_light": round(ex["kernel_ms_light"], 2), "k_trace_p": round(ex["kernel_ms_shadow"], 2),
                                             "k_camera+k_extend_p": round(ex["kernel_ms_closest"], 2), "shade+resolve+k_binary": round(ex["kernel_ms_shade"], 2)},

@@ -10,7 +10,15 @@ light sample) and sorts its VALU instructions into the three issue classes measu
     trans  8.25  v_rcp/sqrt/rsq_f32 (16.5 for f64)
     slow   4.4   everything else: compares, selects, min/max(3), conversions, ldexp, left shifts, bit-field and three-operand integer
                  ops, integer multiplies, packed and f64 arithmetic, DPP moves, lane reads
-The mean cost per VALU instruction gives the issue ceiling of that mix: 1024 SIMDs x 2.4e9 / mean cycles wave-instructions per second.
+Those are the costs of long runs of ONE kind of instruction.  In a mixed stream a slow-class instruction next to fast-class ones costs no more than
+a fast one (same file: PAIR fma | max3 3.14 per instruction against 3.08 and 4.51 alone, PAIR fma | cvt_ubyte 3.15, TRIPLE fma mul | max3 2.45; two
+slow ones next to each other stay slow: PAIR max3 | cvt_ubyte 4.42), while a transcendental adds its full cost (PAIR fma | rcp 6.06 = (3.08 + 8.25) / 2
++ 7 %).  So the issue ceiling of a mix is modelled with two limits, the issue port at the fast rate for every non-transcendental instruction and the
+slow class's own pipe, plus the transcendentals:
+    cycles = max((fast + slow) x 2.7, slow x 4.4) + trans x 8.25 + trans64 x 16.5
+and the ceiling is 1024 SIMDs x 2.4e9 x instructions / cycles wave-instructions per second.  (Round 2 and the first half of round 3 added the
+classes' costs up, which gave 679 G/s for k_light; k_light then measured 774 G/s once its grid let the dispatcher balance it, so the sum was no
+ceiling.  `serial_sum_cycles_per_valu_instruction` keeps that figure for comparison.)
 The count is static (one pass through the loop, cold paths included), so the ceiling is a model, not a measurement; the achieved rate
 that bench.py sets against it is measured (SQ_INSTS_VALU per launch from the PMC passes over the launch time).
 The file is stamped with the hash of the device sources; bench.py ignores it when the hash differs from the tree it runs.
@@ -76,10 +84,14 @@ def main(out):
                 if op.startswith("v_"):
                     mix[issue_class(op)] += 1
             n = sum(mix.values())
-            mean = sum(mix[c] * CYCLES[c] for c in mix) / max(n, 1)
+            serial = sum(mix[c] * CYCLES[c] for c in mix) / max(n, 1)
+            cyc = max((mix["fast"] + mix["slow"]) * CYCLES["fast"], mix["slow"] * CYCLES["slow"]) + mix["trans"] * CYCLES["trans"] + mix["trans64"] * CYCLES["trans64"]
+            mean = cyc / max(n, 1)
             res[name] = {"symbol_prefix": prefix, "loop_valu_instructions": n, "mix": mix, "mean_cycles_per_valu_instruction": round(mean, 3),
+                         "serial_sum_cycles_per_valu_instruction": round(serial, 3),
                          "issue_peak_wave_instructions_per_s": round(1024 * 2.4e9 / mean, 1)}
-    j = {"what": "static issue-class mix of the largest loop of each kernel (tools/isa_mix.py); cycles per class from profiles/r02_valu_rate.txt at 4 waves per SIMD",
+    j = {"what": "static issue-class mix of the largest loop of each kernel (tools/isa_mix.py); cycles per class from profiles/r02_valu_rate.txt at 4 waves per SIMD; "
+                 "ceiling = max((fast + slow) x c_fast, slow x c_slow) + trans x c_trans cycles per pass of the loop (mixed-stream rows of the same file)",
          "cycles_per_class": CYCLES, "simds": 1024, "nominal_clock_hz": 2.4e9, "kernel_source_hash": kernel_source_hash(), "kernels": res}
     open(out, "w").write(json.dumps(j, indent=1) + "\n")
     print(json.dumps(res, indent=1))
