@@ -164,11 +164,12 @@ int rt_occluded_rays(rt_scene* scene, const float* origins, const float* directi
 
 int rt_get_counters(const rt_scene* scene, rt_counters* out);
 /* Options (none changes a result; all but the first three are tuning switches the parity tests flip):
- *   "stats" 0/1 traversal counters; "timing" 0/1 HIP-event kernel timing; "max_paths" camera samples in flight per pass;
+ *   "stats" 0/1 traversal counters; "timing" 0/1 HIP-event kernel timing; "max_paths" camera samples in flight per pass and lane (default 64 Mi;
+ *   halved until the pass buffers fit the device);
  *   "wide" 0/1 is_occluded rays use the 8-wide occlusion BVH (default 1); "persist" 0/1 light samples go through the
  *   k_light + persistent k_trace_p pair (default 1); "hot" 0/1 per-light occluder cache (default 1; only before the first
  *   render); "self_test" 0/1 test the object a shadow ray starts on first (default 1);
- *   "lanes" 1..4 (default 3) render lanes: rt_render / rt_render_device cut the owned pixels into
+ *   "lanes" 1..4 (default 2) render lanes: rt_render / rt_render_device cut the owned pixels into
  *   that many ranges and render them concurrently on internal streams (joined to the caller's stream before the call returns its
  *   work to it), as long as each gets "lane_min_pixels" (65536) pixels; each lane has pass buffers of its own;
  *   "extend_persist" 0/1/2 Scene::intersect rays after the first bounce (2: camera rays too) go through the persistent

@@ -155,8 +155,8 @@ struct rt_scene {
     DevBuf<float> w_rays;   // scratch for arbitrary-ray calls
 
     bool opt_stats = false, opt_timing = false;
-    uint64_t opt_max_paths = 1ull << 25;
-    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 16, opt_phase_bias = 16, opt_shadow_waves = 6, opt_light_waves = 4, opt_hot = 1, opt_extend_persist = 1, opt_extend_refill = 24, opt_extend_inner = 20, opt_extend_grid = 8, opt_lanes = 3, opt_shaft = 8, opt_graze_guard = 0, opt_trace_grid = 8, opt_light_token = 0, opt_light_sum = 1, opt_force_binary = 0, opt_camera_once = 1, opt_light_grid = 0;
+    uint64_t opt_max_paths = 1ull << 26;
+    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 16, opt_phase_bias = 16, opt_shadow_waves = 6, opt_light_waves = 4, opt_hot = 1, opt_extend_persist = 1, opt_extend_refill = 24, opt_extend_inner = 20, opt_extend_grid = 8, opt_lanes = 2, opt_shaft = 8, opt_graze_guard = 0, opt_trace_grid = 8, opt_light_token = 0, opt_light_sum = 1, opt_force_binary = 0, opt_camera_once = 1, opt_light_grid = 0;
     uint64_t opt_lane_min_pixels = 65536;
     uint64_t opt_fail_after_passes = 0;          // test hook: render_impl reports a failure once this many passes are enqueued (0 = never)
     uint32_t grid_max = 2048;
@@ -727,7 +727,7 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
     if (nlL64 >= (1ull << 24)) return fail(RT_ERR_LIMIT, "lights * light_samples too large");
     const uint32_t nlL = (uint32_t)nlL64;
 
-    const uint64_t cap_by_rays = (1ull << 30) / (nlL ? nlL : 1);
+    const uint64_t cap_by_rays = (1ull << 31) / (nlL ? nlL : 1);   // light-sample slots of a pass are indexed with 32 bits
     const uint32_t levels = P.bounces + 1;
     const bool persist = !hemi && nlL > 0 && s->dev.n_wnodes != 0u && s->opt_persist;   // k_light + k_trace_p over the 8-wide occlusion BVH
     const bool in_wave = !persist && nlL > 0 && nlL <= 64 && (64 % nlL) == 0;
@@ -1346,7 +1346,7 @@ int rt_set_option(rt_scene* s, const char* name, uint64_t value) {
     const std::string n(name);
     if (n == "stats") s->opt_stats = value != 0;
     else if (n == "timing") s->opt_timing = value != 0;
-    else if (n == "max_paths") s->opt_max_paths = value ? value : (1ull << 25);
+    else if (n == "max_paths") s->opt_max_paths = value ? value : (1ull << 26);
     else if (n == "self_test") { s->opt_self_test = value ? 1 : 0; s->dev.self_test = s->opt_self_test; }
     else if (n == "wide") { s->opt_wide = value ? 1 : 0; s->dev.n_wnodes = (s->wide.ok && s->opt_wide) ? s->wide.n_nodes() : 0u; }
     else if (n == "persist") s->opt_persist = value ? 1 : 0;

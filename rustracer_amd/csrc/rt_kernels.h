@@ -1661,7 +1661,7 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
     const uint32_t wbase = threadIdx.x & ~63u;
     TravStats tst = {0, 0, 0, 0, 0};
     const uint32_t nlL = pc.nlL;
-    const uint32_t n_rows = ((pc.vcounts[level] + 63u) >> 6) * nlL;             // < 2^25 (render_impl caps paths * nlL at 2^30)
+    const uint32_t n_rows = ((pc.vcounts[level] + 63u) >> 6) * nlL;             // < 2^26 (render_impl caps paths * nlL at 2^31)
     const uint32_t n_win = (n_rows + 63u) >> 6;
     const uint32_t n_waves = gridDim.x * (RT_BLOCK / 64);
     const uint32_t lane = __lane_id();

@@ -391,7 +391,7 @@ def test_render_lanes_do_not_change_a_pixel(scenes):
                 assert np.array_equal(got, ref["rgba"]), (est, shard, lanes, max_paths, int((got != ref["rgba"]).sum()))
                 assert cnt["rays_closest"] == ref["intersect_calls"] and cnt["rays_shadow"] == ref["occluded_calls"], (est, shard, lanes, max_paths)
     finally:
-        gsc.set_option("lanes", 3)
+        gsc.set_option("lanes", 2)
         gsc.set_option("max_paths", 0)
         gsc.set_option("lane_min_pixels", 65536)
         gsc.set_option("light_token", 0)
@@ -1141,7 +1141,7 @@ def test_a_failure_in_mid_frame_joins_the_lanes_and_still_enters_the_collective(
             assert np.array_equal(frame.cpu().numpy(), ref), (lanes, fail_at)
     finally:
         gsc.set_option("fail_after_passes", 0)
-        gsc.set_option("lanes", 3)
+        gsc.set_option("lanes", 2)
         gsc.set_option("lane_min_pixels", 65536)
         gsc.set_option("max_paths", 0)
         comm.destroy()
@@ -1207,7 +1207,7 @@ def test_partial_frames_refine_and_equal_the_oracle_at_the_samples_done(scenes, 
             assert k_done and stop_at * CH <= k_done[0] < SPP, "the interrupted frame is not the oracle's image at a multiple of %d spp" % CH
     finally:
         gsc.set_option("max_paths", 0)
-        gsc.set_option("lanes", 3)
+        gsc.set_option("lanes", 2)
         gsc.set_option("lane_min_pixels", 65536)
 
 
