@@ -105,7 +105,9 @@ int rt_scene_info_get(const rt_scene* scene, rt_scene_info* out);
 /* Where scenes are built.  "device_build" 0/1 (default 1): once rt_init has chosen a GPU, the two trees of a scene with at least
  * "device_build_min" (default 4096) objects are built there (level-synchronous SAH build + 8-wide collapse, the host builders' trees word
  * for word), so that Raytracer::set_scene (src/raytracer.rs:514-518) does not wait for a host build; inputs the device builder declines
- * (a NaN, infinity or negative zero among the coordinates) and smaller scenes are built on the host.  Applies to scenes created afterwards. */
+ * (a NaN, infinity or negative zero among the coordinates) and smaller scenes are built on the host.  Applies to scenes created afterwards.
+ * "alloc_limit" bytes (default 0 = none): test hook, a pass buffer larger than this fails to allocate as if the device were full (the render
+ * then halves its pass size until the buffers fit and remembers that size: rt_get_option "max_paths_fit"). */
 int rt_set_global_option(const char* name, uint64_t value);
 /* Build report of a scene: ms4 = wall milliseconds of the binary tree / the 8-wide tree build, then the part of each between HIP events
  * (uploads, kernels, downloads; 0 when built on the host), on_device2 = 1 where the GPU built it, note = why it did not when it was asked

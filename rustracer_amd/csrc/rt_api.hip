@@ -29,6 +29,7 @@ int g_device = 0;
 bool g_inited = false;          // rt_init has chosen a GPU: scenes may be built there
 uint32_t g_device_build = 1;    // rt_set_global_option("device_build"): build the trees of scenes with >= g_device_build_min objects on the GPU
 uint32_t g_device_build_min = 4096;
+uint64_t g_alloc_limit = 0;      // rt_set_global_option("alloc_limit"), test hook: a pass buffer larger than this many bytes fails to allocate (0: no limit)
 
 int fail(int code, const std::string& msg) {
     g_error = msg;
@@ -80,6 +81,7 @@ struct DevBuf {
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
+        if (g_alloc_limit && (uint64_t)n * sizeof(T) > g_alloc_limit) return fail(RT_ERR_HIP, "buffer beyond the 'alloc_limit' test hook");
         HIP_TRY(hipMalloc((void**)&p, n * sizeof(T)));
         cap = n;
         return RT_OK;
@@ -156,6 +158,7 @@ struct rt_scene {
 
     bool opt_stats = false, opt_timing = false;
     uint64_t opt_max_paths = 1ull << 26;
+    uint64_t max_paths_fit = 0;                  // the pass size the device could hold when a larger one did not fit (0: none failed yet); reset by "max_paths"
     uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 16, opt_phase_bias = 16, opt_shadow_waves = 6, opt_light_waves = 4, opt_hot = 1, opt_extend_persist = 1, opt_extend_refill = 24, opt_extend_inner = 20, opt_extend_grid = 8, opt_lanes = 2, opt_shaft = 8, opt_graze_guard = 0, opt_trace_grid = 8, opt_light_token = 0, opt_light_sum = 1, opt_force_binary = 0, opt_camera_once = 1, opt_light_grid = 0;
     uint64_t opt_lane_min_pixels = 65536;
     uint64_t opt_fail_after_passes = 0;          // test hook: render_impl reports a failure once this many passes are enqueued (0 = never)
@@ -756,7 +759,9 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
     uint32_t npix_chunk = 0, spc = 0;
     // Workspace for `max_paths` camera samples in flight per lane (about 1.8 KB each at 32 light samples, depth 8).  Grow-only; when the
     // device cannot hold it the pass size is halved until it does (results do not depend on the pass size).
-    for (uint64_t max_paths = s->opt_max_paths;; max_paths /= 2) {
+    // (a size that did not fit is not asked for again on the next frame: giving the workspace back and allocating it anew costs seconds)
+    bool shrunk = false;
+    for (uint64_t max_paths = (s->max_paths_fit && s->max_paths_fit < s->opt_max_paths) ? s->max_paths_fit : s->opt_max_paths;; max_paths /= 2, shrunk = true) {
         if (max_paths > cap_by_rays) max_paths = cap_by_rays;
         if (max_paths < 64) max_paths = 64;
         if (lane_pix <= max_paths) {
@@ -794,7 +799,7 @@ int render_impl(rt_scene* s, const rt_render_params* params, uint8_t* rgba_dev, 
             if (!rc) rc = w.stack.ensure(2 * per_level);
             if (!rc) rc = w.radiance.ensure(cap_paths);
         }
-        if (!rc) break;
+        if (!rc) { if (shrunk) s->max_paths_fit = max_paths; break; }
         (void)hipGetLastError();   // clear the out-of-memory error
         if (max_paths <= 65536) return rc;
         // the buffers that did fit at this size would compete with the smaller retry: give the whole workspace back first
@@ -1132,6 +1137,7 @@ int rt_set_global_option(const char* name, uint64_t value) {
     const std::string n(name);
     if (n == "device_build") g_device_build = value ? 1u : 0u;
     else if (n == "device_build_min") g_device_build_min = (uint32_t)value;
+    else if (n == "alloc_limit") g_alloc_limit = value;
     else return fail(RT_ERR_INVALID, "unknown option '" + n + "'");
     return RT_OK;
 }
@@ -1346,7 +1352,7 @@ int rt_set_option(rt_scene* s, const char* name, uint64_t value) {
     const std::string n(name);
     if (n == "stats") s->opt_stats = value != 0;
     else if (n == "timing") s->opt_timing = value != 0;
-    else if (n == "max_paths") s->opt_max_paths = value ? value : (1ull << 26);
+    else if (n == "max_paths") { s->opt_max_paths = value ? value : (1ull << 26); s->max_paths_fit = 0; }
     else if (n == "self_test") { s->opt_self_test = value ? 1 : 0; s->dev.self_test = s->opt_self_test; }
     else if (n == "wide") { s->opt_wide = value ? 1 : 0; s->dev.n_wnodes = (s->wide.ok && s->opt_wide) ? s->wide.n_nodes() : 0u; }
     else if (n == "persist") s->opt_persist = value ? 1 : 0;
@@ -1379,7 +1385,7 @@ int rt_get_option(const rt_scene* s, const char* name, uint64_t* value) {
     if (!s || !name || !value) return fail(RT_ERR_INVALID, "NULL argument");
     const std::string n(name);
     const struct { const char* name; uint64_t v; } table[] = {
-        {"stats", s->opt_stats}, {"timing", s->opt_timing}, {"max_paths", s->opt_max_paths}, {"self_test", s->opt_self_test}, {"wide", s->opt_wide},
+        {"stats", s->opt_stats}, {"timing", s->opt_timing}, {"max_paths", s->opt_max_paths}, {"max_paths_fit", s->max_paths_fit}, {"self_test", s->opt_self_test}, {"wide", s->opt_wide},
         {"persist", s->opt_persist}, {"hot", s->opt_hot}, {"shadow_waves", s->opt_shadow_waves}, {"light_waves", s->opt_light_waves},
         {"refill_min", s->opt_refill_min}, {"phase_bias", s->opt_phase_bias}, {"inner_min", s->opt_inner_min}, {"lanes", s->opt_lanes},
         {"lane_min_pixels", s->opt_lane_min_pixels}, {"extend_persist", s->opt_extend_persist}, {"extend_refill", s->opt_extend_refill},

@@ -487,6 +487,34 @@ def test_axis_aligned_shadow_rays_take_the_binary_tree(gpu):
     assert np.array_equal(gsc.occluded_rays(org, d, md), osc.occluded_rays(org, d, md))
 
 
+def test_pass_size_shrinks_to_what_the_device_holds_and_stays_there(scenes):
+    """When the pass buffers of the configured size cannot be allocated the render gives the workspace back, halves the pass size until it
+    fits, and starts the next frame from the size that fitted (re-allocating a hundred GB per frame costs seconds).  The "alloc_limit" hook
+    makes any buffer beyond 8 MB fail like a full device: same image as the oracle's, twice, the remembered size below the default."""
+    from rustracer_amd._lib import check, lib
+    osc, _ = scenes("teapot")
+    import rustracer_amd as ra
+    from conftest import TEAPOT_OBJ
+    op = oracle_params(width=200, height=150, spp=8, light_samples=4, bounces=3, seed=77)
+    ref = osc.render(op)
+    p = to_rt_params(op)
+    small = ra.Scene._named("teapot", TEAPOT_OBJ)         # a scene handle of its own: the workspace of the shared one is already large
+    gpu_render(small, to_rt_params(oracle_params(width=8, height=8, spp=1, light_samples=1, bounces=1)))     # scene resident, workspace tiny
+    assert small.get_option("max_paths_fit") == 0
+    check(lib().rt_set_global_option(b"alloc_limit", 8 << 20))
+    try:
+        for _ in range(2):
+            got, cnt = gpu_render(small, p)               # 240,000 paths: 15 MB of ray records, 23 MB of path stack
+            assert np.array_equal(got, ref["rgba"])
+            assert cnt["rays_closest"] == ref["intersect_calls"] and cnt["rays_shadow"] == ref["occluded_calls"]
+            fit = small.get_option("max_paths_fit")
+            assert 0 < fit < (1 << 26) and fit * 4 * 16 <= (8 << 20), fit
+        small.set_option("max_paths", 0)                  # setting the option forgets the remembered size
+        assert small.get_option("max_paths_fit") == 0
+    finally:
+        check(lib().rt_set_global_option(b"alloc_limit", 0))
+
+
 def test_render_independent_of_pass_size_and_shards(scenes):
     """Chunking samples/pixels into passes and splitting tiles over shards never changes a pixel."""
     osc, gsc = scenes("teapot")
