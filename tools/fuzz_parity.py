@@ -1,11 +1,15 @@
 """Randomised parity soak: random scenes (new_specular's room + floaters + extra lamps), frame sizes, sample counts, depths and option
-settings, GPU frame and ray counts against the oracle.  python tools/fuzz_parity.py <seed> <cases>"""
+settings, GPU frame and ray counts against the oracle.  python tools/fuzz_parity.py <seed> <cases> [mesh]"""
 import sys, time
 import numpy as np
 sys.path.insert(0, ".")
 sys.path.insert(0, "tests")
 import rustracer_amd as ra
 from test_gpu_parity import oracle_params, to_rt_params, gpu_render, _floaters_scene
+from oracle import binding as ob
+from conftest import TEAPOT_OBJ
+
+KINDS = ("floaters", "dragon", "dragon", "teapot", "specular_teapot", "specular", "diffuse")      # fourth argument "mesh": scenes with meshes too
 
 seed, cases = int(sys.argv[1]), int(sys.argv[2])
 ra._lib.check(ra._lib.lib().rt_init(0))
@@ -16,7 +20,15 @@ bad = 0
 t0 = time.time()
 for c in range(cases):
     n_tri, n_sph, lamps = int(rng.integers(0, 300)), int(rng.integers(0, 40)), int(rng.integers(0, 4))
-    osc, gsc = _floaters_scene(n_tri=max(n_tri, 1), n_sph=max(n_sph, 1), seed=int(rng.integers(1 << 30)), extra_lamps=lamps)
+    kind = KINDS[int(rng.integers(len(KINDS)))] if len(sys.argv) > 3 else "floaters"
+    if kind == "floaters":
+        osc, gsc = _floaters_scene(n_tri=max(n_tri, 1), n_sph=max(n_sph, 1), seed=int(rng.integers(1 << 30)), extra_lamps=lamps)
+    elif kind == "dragon":
+        vp, vn, f = ra.dragon_standin_mesh(int(rng.integers(20, 160)), int(rng.integers(10, 60)))      # 400 .. 19,200 triangles
+        osc, gsc = ob.OracleScene.dragon_mesh(vp, vn, f), ra.Scene.from_dragon_mesh(vp, vn, f)
+    else:
+        osc, gsc = ob.OracleScene.named(kind, TEAPOT_OBJ), ra.Scene._named(kind, TEAPOT_OBJ)
+    n_tri = kind
     if rng.integers(4) == 0:
         gsc.set_option("hot", 0)
     for rep in range(3):
