@@ -371,6 +371,17 @@ def test_beams_settle_rays_without_changing_a_pixel(scenes):
             gsc.set_option("force_binary", 0)
 
 
+def test_random_scenes_frames_and_option_settings(gpu):
+    """tools/fuzz_parity.py in small: random scenes (the room with floaters and extra lamps, dragon-class meshes, the reference's named scenes),
+    frame sizes, sample counts, depths, cameras, estimators and settings of eleven options; image and both ray counts equal the oracle's."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"), "11", "40", "mesh"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "cases 40 x 3 renders, mismatches 0" in r.stdout
+
+
 def test_render_lanes_do_not_change_a_pixel(scenes):
     """rt_render without progress / interrupt words cuts the owned pixels into up to 4 lanes that render concurrently on streams of their own
     (pass buffers and traversal-stack rows per lane).  Pixels are independent, so image and ray counts must equal the oracle's for any number
