@@ -1,5 +1,5 @@
 """Randomised parity soak: random scenes (new_specular's room + floaters + extra lamps), frame sizes, sample counts, depths and option
-settings, GPU frame and ray counts against the oracle.  python tools/fuzz_parity.py <seed> <cases> [mesh]"""
+settings, GPU frame and ray counts against the oracle.  python tools/fuzz_parity.py <seed> <cases> [mesh] [big]"""
 import sys, time
 import numpy as np
 sys.path.insert(0, ".")
@@ -32,7 +32,8 @@ for c in range(cases):
     if rng.integers(4) == 0:
         gsc.set_option("hot", 0)
     for rep in range(3):
-        kw = dict(width=int(rng.integers(1, 140)), height=int(rng.integers(1, 100)), spp=int(rng.integers(1, 7)), light_samples=int(rng.choice([1, 2, 3, 5, 8, 16, 33, 70])),
+        BIG = len(sys.argv) > 4      # fifth argument: frames up to 700 x 500 at up to 12 spp (several lanes, several passes)
+        kw = dict(width=int(rng.integers(1, 700 if BIG else 140)), height=int(rng.integers(1, 500 if BIG else 100)), spp=int(rng.integers(1, 13 if BIG else 7)), light_samples=int(rng.choice([1, 2, 3, 5, 8, 16, 33, 70])),
                   bounces=int(rng.integers(0, 7)), seed=int(rng.integers(1 << 30)), cam=tuple(float(v) for v in rng.uniform([-8, -8, -12], [8, 8, 4])))
         est = int(rng.integers(5) == 0)
         op = oracle_params(direct_estimator=est, **kw)
