@@ -895,6 +895,36 @@ __device__ __forceinline__ uint32_t block_append(bool keep, uint32_t* counter, u
     return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)) * each;
 }
 
+// block_append for B entries per thread with one atomic (see block_append_classed_n).  Order inside the run: wave, then entry k, then lane.
+template <int B>
+__device__ __forceinline__ void block_append_n(const bool (&keep)[B], uint32_t* counter, uint32_t* s_tmp, uint32_t (&pos)[B]) {
+    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+    unsigned long long m[B];
+    uint32_t tot = 0u;
+#pragma unroll
+    for (int k = 0; k < B; ++k) {
+        m[k] = __ballot(keep[k]);
+        tot += (uint32_t)__popcll(m[k]);
+    }
+    if (lane == 0) s_tmp[wave] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < RT_BLOCK / 64; ++w) total += s_tmp[w];
+        s_tmp[RT_BLOCK / 64] = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t base = s_tmp[RT_BLOCK / 64];
+    for (uint32_t w = 0; w < wave; ++w) base += s_tmp[w];
+    __syncthreads();
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int k = 0; k < B; ++k) {
+        pos[k] = base + (uint32_t)__popcll(m[k] & below);
+        base += (uint32_t)__popcll(m[k]);
+    }
+}
+
 // block_append that also groups what it appends by a class 0..2: within the workgroup's run the entries of class 0 come first, then class 1, then
 // class 2 (each in thread order).  k_shade_a uses it to put the vertices whose own-object test takes the same arm of k_light next to each other,
 // so that fewer of k_light's waves run every arm.  s_tmp: 3 * RT_BLOCK / 64 + 1 words.
@@ -918,6 +948,45 @@ __device__ __forceinline__ uint32_t block_append_classed(bool keep, uint32_t cls
     __syncthreads();
     const unsigned long long mine = cls == 0u ? m[0] : (cls == 1u ? m[1] : m[2]);
     return base + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull));
+}
+
+// block_append_classed for B entries per thread and ONE atomic: the same-address atomic with a return value retires at about 10 ns, so one per 256
+// entries bounds a compaction kernel at 25 G entries/s whatever else it does (k_shade_a's largest launch: 259 k atomics, 2.6 of its 3.1 ms).  Order
+// inside the workgroup's run: entry k (i.e. groups of RT_BLOCK consecutive rays, as block_append_classed would have appended them one after the
+// other), then class, then wave, then lane.  s_tmp: 3 * B * RT_BLOCK / 64 + 1 words.
+template <int B>
+__device__ __forceinline__ void block_append_classed_n(const bool (&keep)[B], const uint32_t (&cls)[B], uint32_t* counter, uint32_t* s_tmp, uint32_t (&pos)[B]) {
+    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+    constexpr uint32_t W = RT_BLOCK / 64;
+    unsigned long long m[B][3];
+#pragma unroll
+    for (int k = 0; k < B; ++k)
+#pragma unroll
+        for (uint32_t c = 0; c < 3u; ++c) {
+            m[k][c] = __ballot(keep[k] && cls[k] == c);
+            if (lane == 0) s_tmp[((uint32_t)k * 3u + c) * W + wave] = (uint32_t)__popcll(m[k][c]);
+        }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t i = 0; i < 3u * B * W; ++i) total += s_tmp[i];
+        s_tmp[3 * B * W] = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t run = s_tmp[3 * B * W];
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int k = 0; k < B; ++k) {
+        uint32_t off = 0u;
+#pragma unroll
+        for (uint32_t c = 0; c < 3u; ++c)
+            for (uint32_t w = 0; w < W; ++w) {
+                if (w == wave && cls[k] == c) off = run + (uint32_t)__popcll(m[k][c] & below);
+                run += s_tmp[((uint32_t)k * 3u + c) * W + w];
+            }
+        pos[k] = off;
+    }
+    __syncthreads();
 }
 
 // Sum of v over the workgroup, returned to thread 0 only.  s_tmp: RT_BLOCK / 64 words.
@@ -1198,52 +1267,65 @@ __global__ void __launch_bounds__(RT_BLOCK, 8) k_extend_p(DevScene sc, PassCtx p
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&pc.stats[ST_RAYS_CLOSEST], (unsigned long long)pc.counts[level]);
 }
 
-// cast_ray dispatch (src/raytracer.rs:337-349) up to the point where light sampling starts.
+// cast_ray dispatch (src/raytracer.rs:337-349) up to the point where light sampling starts.  RT_SA_BATCH rays per thread and loop iteration,
+// appended to the vertex queue with one atomic (block_append_classed_n).
+#ifndef RT_SA_BATCH
+#define RT_SA_BATCH 4
+#endif
 __global__ void __launch_bounds__(RT_BLOCK) k_shade_a(DevScene sc, PassCtx pc, uint32_t level) {
     const uint32_t n = pc.counts[level];
     const uint32_t bounces_left = pc.P.bounces - level;
     const float4* ro = pc.ray_o[level & 1];
     const float4* rd = pc.ray_d[level & 1];
-    __shared__ uint32_t s_tmp[3 * (RT_BLOCK / 64) + 1];
+    __shared__ uint32_t s_tmp[3 * RT_SA_BATCH * (RT_BLOCK / 64) + 1];
     uint32_t n_alive = 0, n_alive_tri = 0;
     // rays that found a surface to light are compacted into the vertex queue (misses and depth-0 hits end here)
-    for (uint32_t e0 = blockIdx.x * RT_BLOCK; e0 < n; e0 += gridDim.x * RT_BLOCK) {
-        const uint32_t e = e0 + threadIdx.x;
-        bool alive = false;
-        float4 vp = make_float4(0, 0, 0, 0), vn = vp, vs = vp;
-        uint64_t vr = 0ull;
-        uint32_t id = RT_MISS, cls = 0u;
-        if (e < n) {
-            const float4 o4 = ro[e];
-            const uint32_t slot = __float_as_uint(o4.w);
-            id = pc.hit_id[e];
-            if (id == RT_MISS) {
-                fold_path(pc, slot, level, mk(0.0f, 0.0f, 0.0f));                      // raytracer.rs:348
-            } else {
-                const uint32_t info = object_info(sc, id);
-                const uint32_t mat = info & RT_INFO_MAT;
-                if (bounces_left == 0) {
-                    fold_path(pc, slot, level, xyz(sc.mats[2 * mat + 1]));             // zero_bounce_radiance, raytracer.rs:245-247
+    for (uint32_t e0 = blockIdx.x * (RT_BLOCK * RT_SA_BATCH); e0 < n; e0 += gridDim.x * (RT_BLOCK * RT_SA_BATCH)) {
+        bool alive[RT_SA_BATCH];
+        uint32_t cls[RT_SA_BATCH], q[RT_SA_BATCH];
+        float4 vp[RT_SA_BATCH], vn[RT_SA_BATCH], vs[RT_SA_BATCH];
+        uint64_t vr[RT_SA_BATCH];
+#pragma unroll
+        for (int k = 0; k < RT_SA_BATCH; ++k) {
+            const uint32_t e = e0 + (uint32_t)k * RT_BLOCK + threadIdx.x;
+            alive[k] = false;
+            cls[k] = 0u;
+            vp[k] = vn[k] = vs[k] = make_float4(0, 0, 0, 0);
+            vr[k] = 0ull;
+            if (e < n) {
+                const float4 o4 = ro[e];
+                const uint32_t slot = __float_as_uint(o4.w);
+                const uint32_t id = pc.hit_id[e];
+                if (id == RT_MISS) {
+                    fold_path(pc, slot, level, mk(0.0f, 0.0f, 0.0f));                      // raytracer.rs:348
                 } else {
-                    const vec3 o = xyz(o4), d = xyz(rd[e]);
-                    const float min_dist = pc.hit_t[e] - RT_EPS;                       // RayIntersection::point, mod.rs:58-62
-                    const vec3 p = add(o, scale(d, min_dist));
-                    const vec3 nrm = surface_normal(sc, id, p);
-                    vp = make_float4(p.x, p.y, p.z, __uint_as_float(mat));
-                    vn = make_float4(nrm.x, nrm.y, nrm.z, __uint_as_float(id + 1u));
-                    vs = make_float4(o4.w, d.x, d.y, d.z);
-                    vr = pc.qrng[level & 1][e];
-                    alive = true;
-                    cls = id >= sc.n_tri ? 2u : ((info & RT_INFO_FLAT) ? 0u : 1u);
+                    const uint32_t info = object_info(sc, id);
+                    const uint32_t mat = info & RT_INFO_MAT;
+                    if (bounces_left == 0) {
+                        fold_path(pc, slot, level, xyz(sc.mats[2 * mat + 1]));             // zero_bounce_radiance, raytracer.rs:245-247
+                    } else {
+                        const vec3 o = xyz(o4), d = xyz(rd[e]);
+                        const float min_dist = pc.hit_t[e] - RT_EPS;                       // RayIntersection::point, mod.rs:58-62
+                        const vec3 p = add(o, scale(d, min_dist));
+                        const vec3 nrm = surface_normal(sc, id, p);
+                        vp[k] = make_float4(p.x, p.y, p.z, __uint_as_float(mat));
+                        vn[k] = make_float4(nrm.x, nrm.y, nrm.z, __uint_as_float(id + 1u));
+                        vs[k] = make_float4(o4.w, d.x, d.y, d.z);
+                        vr[k] = pc.qrng[level & 1][e];
+                        alive[k] = true;
+                        cls[k] = id >= sc.n_tri ? 2u : ((info & RT_INFO_FLAT) ? 0u : 1u);
+                        n_alive++;
+                        n_alive_tri += id < sc.n_tri ? 1u : 0u;
+                    }
                 }
             }
         }
         // the order inside the workgroup's run follows the arm of k_light's own-object test: vertices on triangles with an axis-flat box (walls: they
         // walk a beam), on other triangles (mesh: no beam), on spheres (the arm with the square root)
-        const uint32_t q = block_append_classed(alive, cls, &pc.vcounts[level], s_tmp);
-        if (alive) { pc.vP[q] = vp; pc.vN[q] = vn; pc.vS[q] = vs; pc.vR[q] = vr; }
-        n_alive += alive ? 1u : 0u;
-        n_alive_tri += (alive && id < sc.n_tri) ? 1u : 0u;
+        block_append_classed_n<RT_SA_BATCH>(alive, cls, &pc.vcounts[level], s_tmp, q);
+#pragma unroll
+        for (int k = 0; k < RT_SA_BATCH; ++k)
+            if (alive[k]) { pc.vP[q[k]] = vp[k]; pc.vN[q[k]] = vn[k]; pc.vS[q[k]] = vs[k]; pc.vR[q[k]] = vr[k]; }
     }
     // ray and hit counters: one atomic each per workgroup
     const uint32_t t_alive = block_sum_to_thread0(n_alive, s_tmp);
@@ -1767,6 +1849,9 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_trace_p(DevScene sc, PassCt
 #ifndef RT_SB_BATCH
 #define RT_SB_BATCH 2
 #endif
+#ifndef RT_SB_TILES
+#define RT_SB_TILES 4          // vertices per thread and queue reservation
+#endif
 __global__ void __launch_bounds__(RT_BLOCK, RT_SB_WAVES) k_shade_b(DevScene sc, PassCtx pc, uint32_t level) {
     const uint32_t n = pc.vcounts[level];
     const uint32_t bounces_left = pc.P.bounces - level;
@@ -1776,11 +1861,30 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SB_WAVES) k_shade_b(DevScene sc, 
     const float inv_light_samples = 1.0f / (float)L;
     // every thread of a workgroup runs the same number of iterations (block_append has barriers)
     __shared__ uint32_t s_tmp[RT_BLOCK / 64 + 1];
-    for (uint32_t e0 = blockIdx.x * RT_BLOCK; e0 < n; e0 += gridDim.x * RT_BLOCK) {
+    const ulonglong2 jm_path = pc.jump[pc.nlL];
+    for (uint32_t eb = blockIdx.x * (RT_BLOCK * RT_SB_TILES); eb < n; eb += gridDim.x * (RT_BLOCK * RT_SB_TILES)) {
+      // Which of this thread's RT_SB_TILES vertices send their path on is a coin flip on the path's RNG state (weighted_coin_flip, below): it is taken
+      // for all of them first, so that ONE atomic reserves the workgroup's run in the next ray queue (block_append_n); then each vertex in turn.
+      bool goes_on[RT_SB_TILES];
+      uint32_t q_next[RT_SB_TILES];
+#pragma unroll
+      for (int t = 0; t < RT_SB_TILES; ++t) {
+          const uint32_t e = eb + (uint32_t)t * RT_BLOCK + threadIdx.x;
+          goes_on[t] = false;
+          if (e < n && bounces_left != 1) {
+              uint64_t rng = jm_path.x * pc.vR[e] + jm_path.y;
+              goes_on[t] = next_f32(&rng) <= RT_ROULETTE;
+          }
+      }
+      block_append_n<RT_SB_TILES>(goes_on, &pc.counts[level + 1], s_tmp, q_next);
+#pragma unroll 1
+      for (uint32_t t = 0; t < RT_SB_TILES; ++t) {
+        const uint32_t e0 = eb + t * RT_BLOCK;
+        if (e0 >= n) break;
         const uint32_t e = e0 + threadIdx.x;
-        bool cont = false;
-        float4 o_next = make_float4(0, 0, 0, 0), d_next = make_float4(0, 0, 0, 0);
-        uint64_t rng_next = 0ull;
+        uint32_t q = q_next[0];
+#pragma unroll
+        for (int j = 1; j < RT_SB_TILES; ++j) q = t == (uint32_t)j ? q_next[j] : q;
         // whole tiles of 64: the idle lanes of a level's last tile run along on its last vertex (the row masks below are handed from lane to
         // lane, which takes every lane awake) and store nothing
         if ((e & ~63u) < n) {
@@ -1870,8 +1974,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SB_WAVES) k_shade_b(DevScene sc, 
                     if (bounces_left == 1) {
                         fold_path(pc, slot, level, l);                                  // raytracer.rs:340-344
                     } else {
-                        const ulonglong2 jm = pc.jump[pc.nlL];
-                        uint64_t rng = jm.x * pc.vR[e] + jm.y;
+                        uint64_t rng = jm_path.x * pc.vR[e] + jm_path.y;
                         if (!(next_f32(&rng) <= RT_ROULETTE)) {                         // weighted_coin_flip, common.rs:136-138
                             fold_path(pc, slot, level, l);
                         } else {
@@ -1892,18 +1995,16 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SB_WAVES) k_shade_b(DevScene sc, 
                             float4* rec = pc.stack + 2 * ((size_t)slot * pc.stack_depth + level);
                             rec[0] = make_float4(l.x, l.y, l.z, cos_theta);
                             rec[1] = make_float4(reflected.x, reflected.y, reflected.z, pdf);
-                            rng_next = rng;
+                            pc.qrng[(level + 1) & 1][q] = rng;
                             const vec3 dn = unit3(wi);                                  // Ray::new, geo.rs:19-24
-                            o_next = make_float4(p.x, p.y, p.z, __uint_as_float(slot));
-                            d_next = make_float4(dn.x, dn.y, dn.z, 0.0f);
-                            cont = true;
+                            no[q] = make_float4(p.x, p.y, p.z, __uint_as_float(slot));
+                            nd[q] = make_float4(dn.x, dn.y, dn.z, 0.0f);
                         }
                     }
                 }
             }
         }
-        const uint32_t q = block_append(cont, &pc.counts[level + 1], s_tmp);
-        if (cont) { no[q] = o_next; nd[q] = d_next; pc.qrng[(level + 1) & 1][q] = rng_next; }
+      }
     }
 }
 
