@@ -895,34 +895,34 @@ __device__ __forceinline__ uint32_t block_append(bool keep, uint32_t* counter, u
     return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)) * each;
 }
 
-// block_append for B entries per thread with one atomic (see block_append_classed_n).  Order inside the run: wave, then entry k, then lane.
+// block_append for B entries per thread with one atomic (see block_append_classed_n).  Order inside the run: entry k, then wave, then lane, i.e.
+// what B separate appends one after the other would have given.  s_tmp: B * RT_BLOCK / 64 + 1 words.
 template <int B>
 __device__ __forceinline__ void block_append_n(const bool (&keep)[B], uint32_t* counter, uint32_t* s_tmp, uint32_t (&pos)[B]) {
     const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+    constexpr uint32_t W = RT_BLOCK / 64;
     unsigned long long m[B];
-    uint32_t tot = 0u;
 #pragma unroll
     for (int k = 0; k < B; ++k) {
         m[k] = __ballot(keep[k]);
-        tot += (uint32_t)__popcll(m[k]);
+        if (lane == 0) s_tmp[(uint32_t)k * W + wave] = (uint32_t)__popcll(m[k]);
     }
-    if (lane == 0) s_tmp[wave] = tot;
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t total = 0;
-        for (uint32_t w = 0; w < RT_BLOCK / 64; ++w) total += s_tmp[w];
-        s_tmp[RT_BLOCK / 64] = total ? atomicAdd(counter, total) : 0u;
+        for (uint32_t i = 0; i < B * W; ++i) total += s_tmp[i];
+        s_tmp[B * W] = total ? atomicAdd(counter, total) : 0u;
     }
     __syncthreads();
-    uint32_t base = s_tmp[RT_BLOCK / 64];
-    for (uint32_t w = 0; w < wave; ++w) base += s_tmp[w];
-    __syncthreads();
+    uint32_t run = s_tmp[B * W];
     const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
-    for (int k = 0; k < B; ++k) {
-        pos[k] = base + (uint32_t)__popcll(m[k] & below);
-        base += (uint32_t)__popcll(m[k]);
-    }
+    for (int k = 0; k < B; ++k)
+        for (uint32_t w = 0; w < W; ++w) {
+            if (w == wave) pos[k] = run + (uint32_t)__popcll(m[k] & below);
+            run += s_tmp[(uint32_t)k * W + w];
+        }
+    __syncthreads();
 }
 
 // block_append that also groups what it appends by a class 0..2: within the workgroup's run the entries of class 0 come first, then class 1, then
@@ -1860,7 +1860,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SB_WAVES) k_shade_b(DevScene sc, 
     const uint32_t L = pc.P.light_samples;
     const float inv_light_samples = 1.0f / (float)L;
     // every thread of a workgroup runs the same number of iterations (block_append has barriers)
-    __shared__ uint32_t s_tmp[RT_BLOCK / 64 + 1];
+    __shared__ uint32_t s_tmp[RT_SB_TILES * (RT_BLOCK / 64) + 1];
     const ulonglong2 jm_path = pc.jump[pc.nlL];
     for (uint32_t eb = blockIdx.x * (RT_BLOCK * RT_SB_TILES); eb < n; eb += gridDim.x * (RT_BLOCK * RT_SB_TILES)) {
       // Which of this thread's RT_SB_TILES vertices send their path on is a coin flip on the path's RNG state (weighted_coin_flip, below): it is taken
