@@ -1583,6 +1583,21 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
           const LightPdf lp = light_pdf_setup(p, cr);
           vec3 color = mk(0.0f, 0.0f, 0.0f);
           bool sum_open = clear && pc.light_sum != 0u, has_rec = false;
+          // the cache records' fields the sample loop uses, held in scalar registers across it (the compiler otherwise reloads them from the kernel
+          // arguments inside the loop, ten loads each followed by its wait: k_light - 1.3 %)
+          uint32_t hp_kind[RT_HOT], hp_rec[RT_HOT];
+          float hp_a[RT_HOT][3], hp_e1[RT_HOT][3], hp_e2[RT_HOT][3];
+#pragma unroll
+          for (int h = 0; h < RT_HOT; ++h) {
+              const HotRec& hr = hot.rec[hg][h];
+              hp_kind[h] = hr.kind; hp_rec[h] = hr.rec;
+              asm volatile("" : "+s"(hp_kind[h]), "+s"(hp_rec[h]));
+#pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                  hp_a[h][c] = hr.a[c]; hp_e1[h][c] = hr.e1[c]; hp_e2[h][c] = hr.e2[c];
+                  asm volatile("" : "+s"(hp_a[h][c]), "+s"(hp_e1[h][c]), "+s"(hp_e2[h][c]));
+              }
+          }
           for (uint32_t ls = 0; ls < L; ++ls, ++j, row += 64) {                // for _ in 0..light_samples (raytracer.rs:269)
             const vec3 sp = add(xyz(cr), scale(random_sphere(&rng), cr.w));      // Sphere::random_point, objects.rs:223-226
             const vec3 ps = sub(sp, p);
@@ -1628,7 +1643,9 @@ __global__ void __launch_bounds__(RT_BLOCK, WAVES) k_light(DevScene sc, PassCtx 
             }
 #pragma unroll
             for (int h = 0; h < RT_HOT; ++h) {
-                const HotRec& hr = hot.rec[hg][h];      // kernel argument: scalar loads, operands straight from SGPRs
+                HotRec hr;                                // (kernel argument: scalar operands straight from SGPRs)
+                hr.kind = hp_kind[h]; hr.rec = hp_rec[h];
+                for (int c = 0; c < 3; ++c) { hr.a[c] = hp_a[h][c]; hr.e1[c] = hp_e1[h][c]; hr.e2[c] = hp_e2[h][c]; }
                 if (has_hot && hr.kind != 2u && hr.rec != self_rec && !binary && !blocked) {      // (uniform but for the last three)
                     float t = 0.0f;
                     bool ok;
