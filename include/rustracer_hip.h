@@ -177,7 +177,7 @@ int rt_get_counters(const rt_scene* scene, rt_counters* out);
  *   "extend_persist" 0/1/2 Scene::intersect rays after the first bounce (2: camera rays too) go through the persistent
  *   k_extend_p, which refills finished lanes (default 1); "camera_once" 0/1 (default 1): the camera ray of a pixel is traced once per pass
  *   and its hit handed to the pixel's samples of that pass (0: one ray per sample, as the reference casts them);
- *   "shaft" 0..16 (default 8): k_light walks the occlusion BVH once per (vertex, light) with the convex hull of the vertex and
+ *   "shaft" 0..16 (default 6): k_light walks the occlusion BVH once per (vertex, light) with the convex hull of the vertex and
  *   the light's box, visiting at most that many nodes; a beam that can meet no primitive record settles its unblocked rays as visible
  *   and they skip k_trace_p (0 = off); "light_sum" 0/1 (default 1): k_light adds the terms of those rays to the vertex's sum itself, in sample
  *   order, and writes no record for them (0: every visible ray leaves a record for k_shade_b);

@@ -159,7 +159,7 @@ struct rt_scene {
     bool opt_stats = false, opt_timing = false;
     uint64_t opt_max_paths = 1ull << 26;
     uint64_t max_paths_fit = 0;                  // the pass size the device could hold when a larger one did not fit (0: none failed yet); reset by "max_paths"
-    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 16, opt_phase_bias = 16, opt_shadow_waves = 6, opt_light_waves = 4, opt_hot = 1, opt_extend_persist = 1, opt_extend_refill = 24, opt_extend_inner = 20, opt_extend_grid = 8, opt_lanes = 2, opt_shaft = 8, opt_graze_guard = 0, opt_trace_grid = 8, opt_light_token = 0, opt_light_sum = 1, opt_force_binary = 0, opt_camera_once = 1, opt_light_grid = 0;
+    uint32_t opt_inner_min = 12, opt_self_test = 1, opt_wide = 1, opt_persist = 1, opt_refill_min = 16, opt_phase_bias = 16, opt_shadow_waves = 6, opt_light_waves = 4, opt_hot = 1, opt_extend_persist = 1, opt_extend_refill = 24, opt_extend_inner = 20, opt_extend_grid = 8, opt_lanes = 2, opt_shaft = 6, opt_graze_guard = 0, opt_trace_grid = 8, opt_light_token = 0, opt_light_sum = 1, opt_force_binary = 0, opt_camera_once = 1, opt_light_grid = 0;
     uint64_t opt_lane_min_pixels = 65536;
     uint64_t opt_fail_after_passes = 0;          // test hook: render_impl reports a failure once this many passes are enqueued (0 = never)
     uint32_t grid_max = 2048;

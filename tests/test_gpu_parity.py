@@ -278,7 +278,7 @@ def test_occluder_cache_and_scheduling_switches_do_not_change_a_pixel(gpu):
         assert np.array_equal(got, ref["rgba"]), opts
         assert cnt["rays_shadow"] == ref["occluded_calls"] and cnt["rays_closest"] == ref["intersect_calls"], opts
         for k, v in {"self_test": 1, "refill_min": 16, "phase_bias": 16, "shadow_waves": 6, "light_waves": 4, "extend_persist": 1, "extend_refill": 24,
-                     "extend_inner": 20, "extend_grid": 8, "shaft": 8, "camera_once": 1, "light_sum": 1, "light_grid": 0, "trace_grid": 8}.items():
+                     "extend_inner": 20, "extend_grid": 8, "shaft": 6, "camera_once": 1, "light_sum": 1, "light_grid": 0, "trace_grid": 8}.items():
             gsc.set_option(k, v)
     with pytest.raises(Exception):
         gsc.set_option("hot", 0)                           # the cache is chosen at the first render
@@ -366,7 +366,7 @@ def test_beams_settle_rays_without_changing_a_pixel(scenes):
             assert 0 < summed[(1, 1)] < summed[(1, 7)] < summed[(1, 0)], summed      # the earlier the first forced record, the shorter the summed prefix
         finally:
             gsc.set_option("stats", 0)
-            gsc.set_option("shaft", 8)
+            gsc.set_option("shaft", 6)
             gsc.set_option("light_sum", 1)
             gsc.set_option("force_binary", 0)
 
