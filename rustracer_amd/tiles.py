@@ -21,12 +21,17 @@ class Comm:
     def __init__(self, world, rank, broadcast):
         from ._lib import check, lib
         self.world, self.rank = world, rank
-        ident = None
+        ident, failed = None, None
         if rank == 0:
-            buf = (C.c_uint8 * 128)()
-            check(lib().rt_comm_unique_id(buf))
-            ident = bytes(buf)
+            try:
+                buf = (C.c_uint8 * 128)()
+                check(lib().rt_comm_unique_id(buf))
+                ident = bytes(buf)
+            except Exception as e:      # the other ranks are waiting in `broadcast`: hand them the failure (None) before raising it here
+                failed = e
         ident = broadcast(ident)
+        if failed is not None:
+            raise failed
         if not isinstance(ident, (bytes, bytearray)) or len(ident) != 128:
             raise RuntimeError("the RCCL unique id did not arrive (got %r)" % (type(ident),))
         h = C.c_void_p()
